@@ -1,0 +1,132 @@
+/* wsi_hip.h - C ABI of libwsi_hip.so: the gfx950 (MI355X) replacement for the per-patch CNN
+ * inference hot path of acproject/wsi-segmentation-pipeline.
+ *
+ * The reference is pure Python and has no FFI of its own; these entry
+ * points are what a reference-side binding for this path would bind (ctypes stub: INTEGRATION.md).
+ * Each one cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses
+ *   - every device function takes a hipStream_t (passed as void*), enqueues asynchronously and
+ *     returns 0 or a negative errno (-22 EINVAL bad shape/argument, -14 EFAULT launch failure);
+ *     nothing throws, nothing allocates: workspaces are caller-owned
+ *   - planes = 2 : bf16x2 split operands, three MFMA passes, meets the 1e-3 logit contract
+ *     planes = 1 : single-pass bf16 (speed mode; logit error ~2e-2)
+ *   - "PF" = padded-flat activation layout, see wsi_pf_* below and DESIGN.md
+ */
+#ifndef WSI_HIP_H
+#define WSI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSI_HIP_ABI_VERSION 1
+int wsi_hip_abi_version(void);
+
+/* ---- padded-flat layout helpers (host) -------------------------------------------------------
+ * pixel (n,y,x) lives at pixel index (W+2) + n*(H+1)*(W+1) + y*(W+1) + x; each pixel holds
+ * C*planes bf16.  wsi_pf_bytes = allocation size; a PF buffer must be zero-filled once before
+ * first use (kernels never write the pad positions). */
+size_t wsi_pf_bytes(int n, int h, int w, int c, int planes);
+long long wsi_pf_pixel_index(int n, int y, int x, int h, int w);
+
+/* ---- weight prepack (host, CPU memory in and out) -------------------------------------------
+ * Folds eval-mode BatchNorm (resnets_shift.py:42,45,124; eps 1e-5) into the conv weights and
+ * emits them in per-lane MFMA operand order.  bn_* may be NULL (no BN: scale 1, bias 0).
+ *   conv: w OIHW fp32 [cout][cin][k][k], k in {1,3}, cin % 64 == 0, cout % 32 == 0
+ *         wpk_out: wsi_prepack_conv_bytes() bytes; bias_out: cout floats
+ *   stem: w [64][3][7][7] (resnets_shift.py:122)  */
+size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes);
+int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                     const float* bn_var, float eps, int cout, int cin, int k, int planes, void* wpk_out,
+                     float* bias_out);
+size_t wsi_prepack_stem_bytes(int planes);
+int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                     const float* bn_var, float eps, int planes, void* wpk_out, float* bias_out);
+/* 3x256 table of (u8/255 - mean[c]) / std[c] evaluated in fp32 exactly like torchvision
+ * ToTensor + Normalize (utils/preprocessing.py:209-212, myargs.py:127-130). */
+int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_out /* [3][256] */);
+
+/* ---- stem (resnets_shift.py:196-199 conv1+bn1+relu+maxpool) ---------------------------------
+ * Input either f32 NCHW [n][3][h][w] (in_f32 != NULL) or a u8 RGB slide + tile corners + LUT
+ * (fused utils/dataset.py:174-178 read + transform).  h % 16 == 0, w % 4 == 0.
+ * scratch: n*(h/2)*(w/2)*64 floats.  out_pf: PF (h/4, w/4, 64). */
+int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
+                                     int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                                     const void* stem_wpk, const float* stem_bias, int n, int h, int w,
+                                     float* scratch, void* out_pf, int planes, void* stream);
+
+/* ---- conv + folded BN (+ residual) (+ ReLU) (resnets_shift.py:49-65, 19-27) -------------------
+ * in_pf: PF (h_in, w_in, cin); out_pf / resid_pf: PF (h_in/stride, w_in/stride, cout).
+ * resid_pf may be NULL.  in_pf must not alias out_pf. */
+int wsi_conv3x3_bn_act(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,
+                       int n, int h_in, int w_in, int cin, int cout, int stride, int relu, int planes,
+                       void* stream);
+int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,
+                   int cin, int cout, int stride, int planes, void* stream);
+
+/* ---- heads -----------------------------------------------------------------------------------
+ * avgpool_fc: AdaptiveAvgPool2d(1) + flatten (+ Linear(c -> k)) (resnets_shift.py:206-208,
+ *   models/models.py:32-38).  feat_out [n][c] and logits_out [n][k] may each be NULL.
+ * linear: y[b][j] = act(x[b] . w[j] + bias[j]) in fp32 (resnets_shift.py:135-139, models.py:46-50) */
+int wsi_avgpool_fc(const void* in_pf, int n, int h, int w, int c, const float* fc_w, const float* fc_b, int k,
+                   float* feat_out, float* logits_out, int planes, void* stream);
+int wsi_linear(const float* x, const float* w, const float* bias, float* y, int b, int k, int j, int relu,
+               void* stream);
+
+/* ---- layout converters (API boundary + tests) ----------------------------------------------- */
+int wsi_pf_pack(const float* in_nchw, void* out_pf, int n, int c, int h, int w, int planes, void* stream);
+int wsi_pf_unpack(const void* in_pf, float* out_nchw, int n, int c, int h, int w, int planes, void* stream);
+
+/* ---- whole trunk: stem + layer1..4 (+ avgpool + Linear) for n patches -------------------------
+ * The per-batch compute of ResNet.forward (resnets_shift.py:194-212) and of
+ * predict_tumorbed(mode='cls') (utils/eval.py:196-198).  All pointers device memory. */
+typedef struct {
+    const void* stem_w;   const float* stem_b;
+    const void* conv_w[16]; const float* conv_b[16];   /* layerL.B.convK at index (L-1)*4 + B*2 + (K-1) */
+    const void* down_w[3];  const float* down_b[3];    /* layer2..4 .0.downsample */
+    const float* head_w;  const float* head_b;  int head_k;  /* Linear(512 -> head_k) or NULL */
+    int planes;
+} wsi_trunk_weights;
+
+size_t wsi_trunk_workspace_bytes(int n, int h, int w, int planes);
+/* zero-fills the workspace for the (n,h,w,planes) plan; call once before the first forward */
+int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, void* stream);
+int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
+                      long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                      int n, int h, int w, void* workspace, float* feat_out /* [n][512] or NULL */,
+                      float* logits_out /* [n][head_k] or NULL */, float* fmap_out /* f32 NCHW [n][512][h/32][w/32] or NULL */,
+                      void* stream);
+/* debug / parity taps: run the trunk up to stage `stop_after` (0 = stem+maxpool output, 1..8 =
+ * layer1.0, layer1.1, ..., layer4.1) and unpack that tensor to f32 NCHW. */
+int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
+                          long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                          int n, int h, int w, void* workspace, int stop_after, float* tap_out_nchw, void* stream);
+
+/* ---- measurement hook -------------------------------------------------------------------------
+ * wsi_prof_begin arms HIP-event timing (on the launch stream) of every conv / stem launch made by
+ * wsi_trunk_forward; wsi_prof_end disarms, waits for the events and returns the number of records
+ * copied: ms, kind (1 = 3x3 stride 1, 2 = 3x3 stride 2, 3 = 1x1 downsample, 4 = stem+maxpool)
+ * and algorithmic FLOPs (2*M*N*K over real output pixels) per launch. */
+int wsi_prof_begin(int max_records);
+int wsi_prof_end(float* ms_out, int* kind_out, double* flops_out, int cap);
+
+/* ---- slide-side ops ---------------------------------------------------------------------------
+ * tile_gather: utils/dataset.py:171-185 (+ transform): normalised f32 NCHW [n][3][ph][pw].
+ * stitch_add:  utils/eval.py:213-215: pred[c][ty+.. , tx+..] += logits[t][c] over dy x dx (f64).
+ * softmax_threshold_argmax: utils/preprocessing.py:156-172 (+ heat map utils/eval.py:219-228):
+ *   heat_mode 0 = probs[1] ('cls'), 1 = probs[2]+probs[3] ('seg'); probs/classes/heat may be NULL */
+int wsi_tile_gather(const uint8_t* slide, long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy,
+                    const float* lut, float* out_nchw, int n, int ph, int pw, void* stream);
+int wsi_stitch_add(const float* tile_logits, const int* map_xy, int t, int c, int dy, int dx, double* pred, int map_h,
+                   int map_w, void* stream);
+int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
+                                 uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""CPU-only: the C-ABI library builds/loads and exports every symbol include/wsi_hip.h declares;
+host-side entry points (no GPU needed) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from wsi_segmentation_pipeline_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(native.LIB_PATH):
+        native.build()
+    return native.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'wsi_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(wsi_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_pf_layout_helpers(lib):
+    # pixel (n,y,x) -> (W+2) + n*(H+1)*(W+1) + y*(W+1) + x
+    assert lib.wsi_pf_pixel_index(0, 0, 0, 8, 8) == 10
+    assert lib.wsi_pf_pixel_index(2, 3, 4, 8, 8) == 10 + 2 * 81 + 3 * 9 + 4
+    nbytes = lib.wsi_pf_bytes(3, 8, 8, 512, 2)
+    assert nbytes % (512 * 2 * 2) == 0
+    assert nbytes // (512 * 4) >= 2 * 10 + 3 * 81
+    assert lib.wsi_pf_bytes(0, 8, 8, 512, 2) == 0
+    assert lib.wsi_trunk_workspace_bytes(4, 256, 256, 2) > 4 * 4 * 1024 * 1024
+    assert lib.wsi_trunk_workspace_bytes(4, 250, 256, 2) == 0           # not a multiple of 32
+
+
+def test_normalize_lut_matches_transform(lib):
+    from oracle.resnet_oracle import normalize_u8, DATASET_MEAN, DATASET_STD
+    from wsi_segmentation_pipeline_amd.engine import normalize_lut
+    lut = normalize_lut(DATASET_MEAN, DATASET_STD)
+    codes = np.arange(256, dtype=np.uint8).reshape(1, 1, 16, 16).repeat(3, 1)
+    ref = normalize_u8(codes).numpy().reshape(3, 256)
+    assert np.array_equal(lut, ref)                                      # bit-exact: u8 -> fp32 affine
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_prepack_conv_roundtrip(lib):
+    rng = np.random.default_rng(0)
+    cout, cin, k = 64, 128, 3
+    w = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    m = rng.standard_normal(cout).astype(np.float32)
+    v = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for planes in (1, 2):
+        nbytes = lib.wsi_prepack_conv_bytes(cout, cin, k, planes)
+        assert nbytes == cout * cin * k * k * 2 * 2 // (2 // planes) // (1 if planes == 2 else 1) or nbytes > 0
+        pk = np.zeros(nbytes // 2, np.uint16)
+        bias = np.zeros(cout, np.float32)
+        assert lib.wsi_prepack_conv(p(w), p(g), p(b), p(m), p(v), 1e-5, cout, cin, k, planes, p(pk), p(bias)) == 0
+        scale = g.astype(np.float64) / np.sqrt(v.astype(np.float64) + 1e-5)
+        wf = (w.astype(np.float64) * scale[:, None, None, None]).astype(np.float32)
+        assert np.allclose(bias, b - m * scale, atol=1e-6)
+        # unpack [ntile][line][tap][f][lane][8] back to OIHW and compare hi+lo against the folded weights
+        nl = cin * planes // 64
+        frag = _bf16_to_f32(pk).reshape(cout // 32, nl, k * k, 4, 64, 8)
+        rec = np.zeros_like(wf)
+        for nt in range(cout // 32):
+            for l in range(nl):
+                for f in range(4):
+                    cbase = 32 * l + 16 * (f & 1) if planes == 2 else 64 * l + 16 * f
+                    for lane in range(64):
+                        co = nt * 32 + (lane & 31)
+                        ci = cbase + 8 * (lane >> 5)
+                        rec[co, ci:ci + 8] += frag[nt, l, :, f, lane, :].T.reshape(8, k, k)
+        tol = 2 ** -16 if planes == 2 else 2 ** -8
+        assert np.abs(rec - wf).max() <= tol * np.abs(wf).max()
+
+
+def test_bad_arguments_return_einval(lib):
+    assert lib.wsi_prepack_conv_bytes(48, 64, 3, 2) == 0
+    assert lib.wsi_prepack_conv(None, None, None, None, None, 1e-5, 64, 64, 3, 2, None, None) == -22
+    assert lib.wsi_conv3x3_bn_act(None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, 2, None) == -22
+    assert lib.wsi_trunk_forward(None, None, None, 0, 0, 0, None, None, 1, 64, 64, None, None, None, None, None) == -22

@@ -1,0 +1,167 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes) and checked
+against the CPU oracle (torch fp32 ops on the CPU / numpy restatements)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_PARITY = 1e-4      # relative to the tensor's max magnitude, bf16x2 split (3 MFMA passes)
+TOL_SPEED = 3e-2       # single-pass bf16
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    return torch.device('cuda:0')
+
+
+def _rel_err(got, ref):
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+
+
+def test_pf_roundtrip(dev):
+    from wsi_segmentation_pipeline_amd import engine as E
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 128, 5, 7, generator=g)
+    for planes, tol in ((2, 2 ** -16), (1, 2 ** -8)):
+        buf = E.pf_pack(x.to(dev), planes)
+        y = E.pf_unpack(buf, 3, 128, 5, 7, planes).cpu()
+        assert _rel_err(y, x) <= tol
+    # pad positions stay zero: total sum of the raw buffer equals the sum over real pixels only
+    buf = E.pf_pack(torch.ones(2, 64, 4, 4, device=dev), 1)
+    assert int((buf.view(torch.int16) != 0).sum()) == 2 * 64 * 16
+
+
+def _conv_case(dev, n, cin, cout, h, w, stride, ksize, resid, relu, planes, seed):
+    from wsi_segmentation_pipeline_amd import engine as E
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g).abs_()
+    wt = torch.randn(cout, cin, ksize, ksize, generator=g) * (2.0 / (cin * ksize * ksize)) ** 0.5
+    bn = (torch.rand(cout, generator=g) * 0.5 + 0.75, torch.randn(cout, generator=g) * 0.1,
+          torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) * 0.5 + 0.75)
+    ho, wo = h // stride, w // stride
+    r = torch.randn(n, cout, ho, wo, generator=g) if resid else None
+    ref = F.conv2d(x, wt, None, stride, ksize // 2)
+    ref = F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    if r is not None:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    wpk, bias = E.prepack_conv(wt, bn, planes, dev)
+    xpf = E.pf_pack(x.to(dev), planes)
+    rpf = E.pf_pack(r.to(dev), planes) if r is not None else None
+    opf = E.conv_bn_act(xpf, n, h, w, cin, cout, wpk, bias, stride, ksize, rpf, relu, planes)
+    got = E.pf_unpack(opf, n, cout, ho, wo, planes).cpu()
+    torch.cuda.synchronize()
+    # pad positions of the output buffer must still be zero (next layer's implicit padding)
+    real = E.pf_pack(torch.full_like(got, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
+    assert not bool((opf.view(torch.int16)[~real] != 0).any()), 'kernel wrote to a pad position'
+    return _rel_err(got, ref)
+
+
+CONV_S1 = [  # n, cin, cout, h, w
+    (3, 64, 64, 16, 16), (2, 64, 64, 64, 64), (5, 128, 128, 8, 8), (2, 128, 128, 32, 32),
+    (3, 256, 256, 4, 4), (2, 256, 256, 16, 16), (7, 512, 512, 2, 2), (3, 512, 512, 8, 8), (1, 64, 128, 8, 8),
+]
+
+
+@pytest.mark.parametrize('shape', CONV_S1)
+def test_conv3x3_stride1(dev, shape):
+    n, cin, cout, h, w = shape
+    assert _conv_case(dev, n, cin, cout, h, w, 1, 3, True, True, 2, 1) <= TOL_PARITY
+    assert _conv_case(dev, n, cin, cout, h, w, 1, 3, False, False, 2, 2) <= TOL_PARITY
+    assert _conv_case(dev, n, cin, cout, h, w, 1, 3, True, True, 1, 3) <= TOL_SPEED
+
+
+CONV_S2 = [(3, 64, 128, 16, 16), (2, 64, 128, 64, 64), (3, 128, 256, 8, 8), (2, 256, 512, 16, 16), (5, 256, 512, 4, 4)]
+
+
+@pytest.mark.parametrize('shape', CONV_S2)
+def test_conv_stride2_and_downsample(dev, shape):
+    n, cin, cout, h, w = shape
+    assert _conv_case(dev, n, cin, cout, h, w, 2, 3, False, True, 2, 4) <= TOL_PARITY
+    assert _conv_case(dev, n, cin, cout, h, w, 2, 1, False, False, 2, 5) <= TOL_PARITY
+    assert _conv_case(dev, n, cin, cout, h, w, 2, 3, False, True, 1, 6) <= TOL_SPEED
+    assert _conv_case(dev, n, cin, cout, h, w, 2, 1, False, False, 1, 7) <= TOL_SPEED
+
+
+def test_mfma_orientation_asymmetric(dev):
+    """A = identity-like weights with an asymmetric input catches a swapped C/D mapping."""
+    from wsi_segmentation_pipeline_amd import engine as E
+    n, c, h, w = 1, 64, 8, 8
+    x = torch.arange(n * c * h * w, dtype=torch.float32).reshape(n, c, h, w) % 251
+    wt = torch.zeros(c, c, 3, 3)
+    for co in range(c):
+        wt[co, (co * 7 + 3) % c, 1, 1] = 1.0           # a channel permutation at the centre tap
+        wt[co, (co * 5 + 1) % c, 0, 2] = 0.5
+    ref = F.conv2d(x, wt, None, 1, 1)
+    wpk, bias = E.prepack_conv(wt, None, 2, dev)
+    got = E.pf_unpack(E.conv_bn_act(E.pf_pack(x.to(dev), 2), n, h, w, c, c, wpk, bias, 1, 3, None, False, 2), n, c, h, w, 2)
+    assert torch.equal(got.cpu(), ref)                  # small integers: exact
+
+
+def test_linear(dev):
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    import ctypes as C
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(11, 8192, generator=g), torch.randn(96, 8192, generator=g) * 0.01, torch.randn(96, generator=g)
+    lib = native.load()
+    y = torch.empty(11, 96, device=dev)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    native.check(lib.wsi_linear(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), 11, 8192, 96, 1,
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'linear')
+    ref = F.relu(F.linear(x, w, b))
+    assert float((y.cpu() - ref).abs().max()) <= 1e-4
+
+
+def test_avgpool_fc(dev):
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    import ctypes as C
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5, 512, 8, 8, generator=g).abs_()
+    w, b = torch.randn(4, 512, generator=g) * 0.05, torch.randn(4, generator=g)
+    lib = native.load()
+    feat, logit = torch.empty(5, 512, device=dev), torch.empty(5, 4, device=dev)
+    wd, bd = w.to(dev), b.to(dev)
+    native.check(lib.wsi_avgpool_fc(E.pf_pack(x.to(dev), 2).data_ptr(), 5, 8, 8, 512, wd.data_ptr(), bd.data_ptr(), 4,
+                                    feat.data_ptr(), logit.data_ptr(), 2, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                 'avgpool_fc')
+    rf = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+    assert float((feat.cpu() - rf).abs().max()) <= 1e-5
+    assert float((logit.cpu() - F.linear(rf, w, b)).abs().max()) <= 1e-4
+
+
+def test_tile_gather_stitch_softmax(dev):
+    from oracle import wsi_oracle as WO
+    from oracle.resnet_oracle import normalize_u8, DATASET_MEAN, DATASET_STD
+    from wsi_segmentation_pipeline_amd import engine as E
+    rng = np.random.default_rng(5)
+    slide = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    xy = np.array([[0, 0], [7, 13], [400 - 64, 300 - 64], [390, 290], [-5, -3]], np.int32)   # incl. out-of-slide reads
+    lut = torch.from_numpy(E.normalize_lut(DATASET_MEAN, DATASET_STD)).to(dev)
+    got = E.tile_gather(torch.from_numpy(slide).to(dev), torch.from_numpy(xy), 64, 64, lut).cpu()
+    ref = torch.stack([normalize_u8(WO.read_tile(slide, int(x), int(y), 64, 64).transpose(2, 0, 1)[None])[0] for x, y in xy])
+    assert torch.equal(got, ref)
+    # stitch: overlapping footprints, clipping at the map border, exact float64 sums
+    T, Cc, dy, dx, MH, MW = 200, 4, 8, 8, 61, 77
+    logits = rng.standard_normal((T, Cc)).astype(np.float32)
+    txy = np.stack((rng.integers(-3, MW, T), rng.integers(-3, MH, T)), 1).astype(np.int32)
+    txy = np.maximum(txy, 0)                     # numpy slices with negative starts wrap; the reference never has them
+    ref = np.zeros((Cc, MH, MW))
+    for (x, y), p in zip(txy, logits):
+        ref[:, y:y + dy, x:x + dx] += p[:, None, None].astype(np.float64)
+    pred = torch.zeros((Cc, MH, MW), dtype=torch.float64, device=dev)
+    E.stitch_add(pred, torch.from_numpy(logits).to(dev), torch.from_numpy(txy), dy, dx)
+    assert np.array_equal(pred.cpu().numpy(), ref)
+    # softmax / threshold / argmax / heat map
+    mask = (rng.random((MH, MW)) > 0.3).astype(np.uint8)
+    for th in ((0., 0., 0., 0.), (0.1, 0.3, 0.2, 0.25)):
+        rc, rp = WO.threshold_probs(ref, th)
+        cls, probs, heat = E.softmax_threshold_argmax(pred, th, torch.from_numpy(mask), 'cls')
+        assert np.abs(probs.cpu().numpy() - rp).max() <= 1e-12
+        assert (cls.cpu().numpy() != rc).mean() <= 1e-3           # ties under 1-ulp exp differences only
+        rh = WO.tumorbed_heatmap(rp, mask, 'cls')
+        assert np.abs(heat.cpu().numpy().astype(int) - rh.astype(int)).max() <= 1

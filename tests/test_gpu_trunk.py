@@ -1,0 +1,110 @@
+"""GPU parity of the whole trunk against the golden vectors generated from the reference
+(tests/golden, oracle/gen_golden.py) and against the CPU oracle's intermediate activations.
+Contract (BASELINE.json north_star): max abs logit error <= 1e-3 vs the reference fp32 CPU path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resnet_oracle as R
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 on the output logits"
+TAPS = ['pool'] + ['layer%d.%d' % (l, b) for l in (1, 2, 3, 4) for b in (0, 1)]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def sd():
+    return W.make_resnet18_state_dict(11)
+
+
+def test_taps_vs_oracle_64(dev, sd):
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    u8 = W.make_u8_patches(12, (2, 16, 3, 64, 64)).reshape(-1, 3, 64, 64)[:6]
+    x = R.normalize_u8(u8)
+    taps = {}
+    with torch.no_grad():
+        R.trunk(sd, x, taps)
+    eng = TrunkEngine(sd, dev, planes=2)
+    report = []
+    for i, name in enumerate(TAPS):
+        got = eng.forward_f32(x.to(dev), tap=i).cpu()
+        ref = taps[name]
+        assert got.shape == ref.shape, name
+        err = float((got - ref).abs().max() / ref.abs().max())
+        report.append((name, err))
+    print('tap errors (rel to max):', report)
+    for name, err in report:
+        assert err <= 2e-4, report
+
+
+def test_u8_slide_path_equals_f32_path(dev, sd):
+    """Fused tile read + LUT transform in the stem == gather + normalise on the host side."""
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    rng = np.random.default_rng(7)
+    slide = rng.integers(0, 256, (200, 260, 3), dtype=np.uint8)
+    xy = np.array([[0, 0], [100, 50], [260 - 64, 200 - 64], [230, 170]], np.int32)     # last one hangs over the edge
+    from oracle import wsi_oracle as WO
+    tiles = np.stack([WO.read_tile(slide, int(x), int(y), 64, 64) for x, y in xy]).transpose(0, 3, 1, 2)
+    eng = TrunkEngine(sd, dev, planes=2)
+    a = eng.forward_tiles(torch.from_numpy(slide).to(dev), torch.from_numpy(xy).to(dev), 64, 64, feat=True, logits=False)[0]
+    b = eng.forward_f32(R.normalize_u8(tiles).to(dev), feat=True)[0]
+    assert torch.equal(a, b)
+
+
+def _bag(dev, sd, name, planes, golden_dir):
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    g = np.load(os.path.join(golden_dir, name))
+    shape = tuple(int(v) for v in g['input_shape'])
+    B, P = shape[:2]
+    u8 = W.make_u8_patches(int(g['input_seed']), shape).reshape(-1, *shape[2:])      # image index b*P + p
+    eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']))
+    feat, logits, _ = eng.forward_f32(R.normalize_u8(u8).to(dev), feat=True, logits=True)
+    singles = logits.view(B, P, 4).transpose(0, 1).reshape(P * B, 4)                  # row = p*B + b
+    h = eng.linear(feat.view(B, P * 512), sd['fc.0.weight'], sd['fc.0.bias'], relu=True)
+    ens = eng.linear(h, sd['fc.2.weight'], sd['fc.2.bias'])
+    return (float(np.abs(singles.cpu().numpy() - g['singles']).max()), float(np.abs(ens.cpu().numpy() - g['ensemble']).max()))
+
+
+def test_golden_bag64(dev, sd, golden_dir):
+    e1, e2 = _bag(dev, sd, 'resnet18_bag64.npz', 2, golden_dir)
+    print('bag64 parity-mode max abs err: singles %.2e ensemble %.2e' % (e1, e2))
+    assert e1 <= LOGIT_TOL and e2 <= LOGIT_TOL
+
+
+def test_golden_cfg1_256(dev, sd, golden_dir):
+    e1, e2 = _bag(dev, sd, 'resnet18_cfg1_256.npz', 2, golden_dir)
+    print('cfg1 256x256 parity-mode max abs err: singles %.2e ensemble %.2e' % (e1, e2))
+    assert e1 <= LOGIT_TOL and e2 <= LOGIT_TOL
+
+
+def test_speed_mode_error_is_reported_not_claimed(dev, sd, golden_dir):
+    """Single-pass bf16 does NOT meet 1e-3; keep it honest and bounded."""
+    e1, e2 = _bag(dev, sd, 'resnet18_cfg1_256.npz', 1, golden_dir)
+    print('cfg1 256x256 speed-mode (single-pass bf16) max abs err: singles %.2e ensemble %.2e' % (e1, e2))
+    assert e1 <= 0.15 and e2 <= 0.15
+
+
+def test_golden_tile_logits_256(dev, sd, golden_dir):
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    g = np.load(os.path.join(golden_dir, 'tile_logits_256.npz'))
+    cls = W.make_head_state_dict(int(g['cls_seed']), 'classifier')
+    u8 = W.make_u8_patches(int(g['input_seed']), tuple(int(v) for v in g['input_shape']))
+    eng = TrunkEngine(sd, dev, planes=2, head=(cls['fc.0.weight'], cls['fc.0.bias']))
+    # feed the tiles as a vertical strip "slide" through the fused u8 path
+    strip = np.ascontiguousarray(u8.transpose(0, 2, 3, 1).reshape(-1, 256, 3))
+    xy = np.stack((np.zeros(8, np.int32), np.arange(8, dtype=np.int32) * 256), 1)
+    _, logits, fmap = eng.forward_tiles(torch.from_numpy(strip).to(dev), torch.from_numpy(xy).to(dev), 256, 256,
+                                        logits=True, fmap=True)
+    err = float(np.abs(logits.cpu().numpy() - g['logits']).max())
+    ferr = float(np.abs(fmap.cpu().numpy()[:, ::16] - g['fmap_sub']).max())
+    print('tile logits max abs err %.2e, feature map err %.2e' % (err, ferr))
+    assert err <= LOGIT_TOL and ferr <= 1e-3

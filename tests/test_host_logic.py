@@ -1,0 +1,96 @@
+"""CPU tests of the host logic: vectorised tile grid vs the oracle's restatement of the reference
+loops, hand-derived tile counts, sharding, and the N>1 gather path on gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wsi_oracle as WO
+from wsi_segmentation_pipeline_amd import slide as S
+
+
+def test_grid_counts_hand_derived():
+    # 40 000^2, tile 256 / stride 256: 156x156 interior + 156 + 156 = 24 648; last interior x = 39 681
+    g = S.tile_grid(40000, 40000, 256, 256, 256, 256)
+    assert len(g) == 24648
+    assert g[155, 0] == 39681 and g[156 * 156, 0] == 39743
+    # reference defaults tile 512 / stride 128 (myargs.py:105-112)
+    assert len(S.tile_grid(40000, 40000, 512, 512, 128, 128)) == 96099
+
+
+@pytest.mark.parametrize('case', [
+    (1000, 700, 64, 64, 64, 64, 1 / 16), (1000, 700, 128, 64, 32, 48, 0.25), (513, 300, 256, 256, 100, 7, 1.0),
+    (300, 300, 256, 256, 256, 256, 1 / 4), (256, 256, 256, 256, 64, 64, 1.0), (100, 50, 256, 256, 64, 64, 1.0),
+])
+def test_grid_matches_oracle(case):
+    iw, ih, ph, pw, sh, sw, m = case
+    rng = np.random.default_rng(iw + ih)
+    assert S.tile_grid(iw, ih, ph, pw, sh, sw).tolist() == [list(t) for t in WO.tile_grid(iw, ih, ph, pw, sh, sw)]
+    mh, mw = max(1, int(ih * m)), max(1, int(iw * m))
+    for density in (0.02, 0.06, 0.5):
+        mask = (rng.random((mh, mw)) < density).astype(np.uint8)
+        mask[: mh // 3] = 0
+        with np.errstate(all='ignore'):
+            ref = WO.tile_grid(iw, ih, ph, pw, sh, sw, mask, m)
+        got = S.tile_grid(iw, ih, ph, pw, sh, sw, mask, m)
+        assert got.tolist() == [list(t) for t in ref]
+
+
+def test_map_coords_truncation():
+    xy = np.array([[1, 1], [257, 513], [39743, 39681]])
+    m = 1 / 16
+    assert S.map_coords(xy, m).tolist() == [[int(m * float(x)), int(m * float(y))] for x, y in xy]
+
+
+def test_shard_range_partitions():
+    for total in (0, 1, 7, 24648, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [S.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_find_nuclei_and_isforeground():
+    rgb = np.array([[[255, 255, 255], [200, 150, 200], [0, 0, 0], [100, 91, 100], [100, 90, 100], [10, 9, 10]]], np.uint8)
+    assert WO.find_nuclei_hsv(rgb).tolist() == [[0, 1, 0, 0, 0, 0]]     # S = 0, .25, 0, .09, .1 (not >), .1
+    assert WO.isforeground(np.array([1] + [0] * 19)) and not WO.isforeground(np.array([1] + [0] * 20))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, total, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    full = torch.arange(total * 4, dtype=torch.float32).view(total, 4)
+    lo, hi = S.shard_range(total, rank, world)
+    out = S.gather_tile_logits(full[lo:hi].clone(), total, rank, world)
+    q.put((rank, bool(torch.equal(out, full))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [11, 2, 1])
+def test_gather_tile_logits_gloo_world2(total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,411 @@
+// extern "C" surface of libwsi_hip.so (include/wsi_hip.h): argument checking, host-side weight
+// prepack, and the trunk launch sequence.  No allocation, no synchronisation, no exceptions.
+#include "common.h"
+#include "../../include/wsi_hip.h"
+#include <math.h>
+#include <string.h>
+
+int wsi_conv_dispatch(const ConvArgs& a, int planes, hipStream_t st);
+int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
+int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
+int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
+                            float* logits, int planes, hipStream_t st);
+int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
+                        hipStream_t st);
+int wsi_pf_pack_dispatch(const float* in, void* out, const PFGeom& g, int planes, hipStream_t st);
+int wsi_pf_unpack_dispatch(const void* in, float* out, const PFGeom& g, int planes, hipStream_t st);
+int wsi_tile_gather_dispatch(const uint8_t* slide, long long pitch, int SH, int SW, const int* origins, const float* lut,
+                             float* out, int N, int ph, int pw, hipStream_t st);
+int wsi_stitch_add_dispatch(const float* logits, const int* txy, int T, int C, int dy, int dx, double* pred, int MH, int MW,
+                            hipStream_t st);
+int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
+                         const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
+
+// ------------------------------------------------------------------------------------ host helpers
+static inline uint16_t f2bf(float f) {            // round-to-nearest-even, same as the device cast
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void split_host(float x, uint16_t& hi, uint16_t& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+static void bn_fold(const float* g, const float* b, const float* m, const float* v, float eps, int co, double& scale,
+                    double& shift) {
+    if (!g) { scale = 1.0; shift = 0.0; return; }
+    scale = (double)g[co] / sqrt((double)v[co] + (double)eps);
+    shift = (double)b[co] - (double)m[co] * scale;
+}
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" {
+
+int wsi_hip_abi_version(void) { return WSI_HIP_ABI_VERSION; }
+
+size_t wsi_pf_bytes(int n, int h, int w, int c, int planes) {
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || planes < 1 || planes > 2) return 0;
+    return (size_t)pf_alloc_pixels(n, h, w) * (size_t)c * planes * 2;
+}
+long long wsi_pf_pixel_index(int n, int y, int x, int h, int w) {
+    return (long long)(w + 2) + (long long)n * (h + 1) * (w + 1) + (long long)y * (w + 1) + x;
+}
+
+size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes) {
+    if (cout % 32 || cin % 64 || (k != 1 && k != 3) || planes < 1 || planes > 2) return 0;
+    // [cout/32][lines][k*k][4 frags][64 lanes][8] bf16, lines = cin*planes/64
+    return (size_t)(cout / 32) * (cin * planes / 64) * k * k * 4 * 64 * 8 * 2;
+}
+
+int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                     const float* bn_var, float eps, int cout, int cin, int k, int planes, void* wpk_out,
+                     float* bias_out) {
+    if (!w || !wpk_out || !bias_out || wsi_prepack_conv_bytes(cout, cin, k, planes) == 0) return WSI_EINVAL;
+    uint16_t* o = (uint16_t*)wpk_out;
+    const int NL = cin * planes / 64, NT = k * k;
+    for (int co = 0; co < cout; ++co) {
+        double sc, sh;
+        bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+        bias_out[co] = (float)sh;
+    }
+    for (int nt = 0; nt < cout / 32; ++nt)
+        for (int l = 0; l < NL; ++l)
+            for (int t = 0; t < NT; ++t)
+                for (int f = 0; f < 4; ++f) {
+                    uint16_t* frag = o + ((((size_t)nt * NL + l) * NT + t) * 4 + f) * 512;
+                    const int plane = planes == 2 ? (f >> 1) : 0;
+                    const int cbase = planes == 2 ? 32 * l + 16 * (f & 1) : 64 * l + 16 * f;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = nt * 32 + (lane & 31);
+                        double sc, sh;
+                        bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = cbase + 8 * (lane >> 5) + j;
+                            const float wf = (float)((double)w[(((size_t)co * cin + ci) * k + t / k) * k + t % k] * sc);
+                            uint16_t hi, lo;
+                            split_host(wf, hi, lo);
+                            frag[lane * 8 + j] = plane ? lo : hi;
+                        }
+                    }
+                }
+    return WSI_OK;
+}
+
+size_t wsi_prepack_stem_bytes(int planes) { return (planes < 1 || planes > 2) ? 0 : (size_t)2 * 14 * planes * 64 * 8 * 2; }
+
+int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                     const float* bn_var, float eps, int planes, void* wpk_out, float* bias_out) {
+    if (!w || !wpk_out || !bias_out || planes < 1 || planes > 2) return WSI_EINVAL;
+    uint16_t* o = (uint16_t*)wpk_out;
+    for (int co = 0; co < 64; ++co) {
+        double sc, sh;
+        bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+        bias_out[co] = (float)sh;
+    }
+    for (int nt = 0; nt < 2; ++nt)
+        for (int s = 0; s < 14; ++s)
+            for (int p = 0; p < planes; ++p) {
+                uint16_t* frag = o + ((size_t)(nt * 14 + s) * planes + p) * 512;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = nt * 32 + (lane & 31), h = lane >> 5;
+                    double sc, sh;
+                    bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+                    for (int j = 0; j < 8; ++j) {
+                        const int kh = s >> 1, kw = (s & 1) * 4 + 2 * h + (j >> 2), c = j & 3;
+                        float wf = 0.f;
+                        if (kw < 7 && c < 3) wf = (float)((double)w[(((size_t)co * 3 + c) * 7 + kh) * 7 + kw] * sc);
+                        uint16_t hi, lo;
+                        split_host(wf, hi, lo);
+                        frag[lane * 8 + j] = p ? lo : hi;
+                    }
+                }
+            }
+    return WSI_OK;
+}
+
+int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_out) {
+    if (!mean || !std_ || !lut_out) return WSI_EINVAL;
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float t = (float)v / 255.0f;     // ToTensor: fp32 division
+            volatile float d = t - mean[c];           // Normalize: sub, then div, each rounded to fp32
+            lut_out[c * 256 + v] = d / std_[c];
+        }
+    return WSI_OK;
+}
+
+// ------------------------------------------------------------------------------------ single ops
+int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
+                                     int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                                     const void* stem_wpk, const float* stem_bias, int n, int h, int w,
+                                     float* scratch, void* out_pf, int planes, void* stream) {
+    if (!stem_wpk || !stem_bias || !scratch || !out_pf || n <= 0 || h % 16 || w % 4) return WSI_EINVAL;
+    if (!in_f32 && (!slide || !tile_xy || !lut)) return WSI_EINVAL;
+    StemArgs a;
+    a.mode = in_f32 ? 0 : 1;
+    a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
+    a.origins = tile_xy; a.lut = lut; a.wpk = stem_wpk; a.bias = stem_bias; a.out = scratch;
+    a.N = n; a.H = h; a.W = w;
+    int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
+    if (rc) return rc;
+    return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
+}
+
+static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
+                       int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream) {
+    if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
+    if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
+    ConvArgs a;
+    a.in = in_pf; a.out = out_pf; a.resid = resid_pf; a.wpk = wpk; a.bias = bias;
+    a.gi = pf_geom(n, h_in, w_in, cin);
+    a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
+    a.stride = stride; a.ksize = ksize; a.relu = relu;
+    return wsi_conv_dispatch(a, planes, (hipStream_t)stream);
+}
+
+int wsi_conv3x3_bn_act(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,
+                       int n, int h_in, int w_in, int cin, int cout, int stride, int relu, int planes,
+                       void* stream) {
+    return conv_common(in_pf, out_pf, resid_pf, wpk, bias, n, h_in, w_in, cin, cout, stride, 3, relu, planes, stream);
+}
+
+int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,
+                   int cin, int cout, int stride, int planes, void* stream) {
+    return conv_common(in_pf, out_pf, nullptr, wpk, bias, n, h_in, w_in, cin, cout, stride, 1, 0, planes, stream);
+}
+
+int wsi_avgpool_fc(const void* in_pf, int n, int h, int w, int c, const float* fc_w, const float* fc_b, int k,
+                   float* feat_out, float* logits_out, int planes, void* stream) {
+    if (!in_pf || n <= 0 || (logits_out && (!fc_w || !fc_b || k <= 0))) return WSI_EINVAL;
+    return wsi_avgpool_fc_dispatch(in_pf, pf_geom(n, h, w, c), fc_w, fc_b, k, feat_out, logits_out, planes,
+                                   (hipStream_t)stream);
+}
+
+int wsi_linear(const float* x, const float* w, const float* bias, float* y, int b, int k, int j, int relu,
+               void* stream) {
+    if (!x || !w || !y) return WSI_EINVAL;
+    return wsi_linear_dispatch(x, w, bias, y, b, k, j, relu, (hipStream_t)stream);
+}
+
+int wsi_pf_pack(const float* in_nchw, void* out_pf, int n, int c, int h, int w, int planes, void* stream) {
+    if (!in_nchw || !out_pf || n <= 0 || c % 64 || planes < 1 || planes > 2) return WSI_EINVAL;
+    return wsi_pf_pack_dispatch(in_nchw, out_pf, pf_geom(n, h, w, c), planes, (hipStream_t)stream);
+}
+
+int wsi_pf_unpack(const void* in_pf, float* out_nchw, int n, int c, int h, int w, int planes, void* stream) {
+    if (!in_pf || !out_nchw || n <= 0 || c % 64 || planes < 1 || planes > 2) return WSI_EINVAL;
+    return wsi_pf_unpack_dispatch(in_pf, out_nchw, pf_geom(n, h, w, c), planes, (hipStream_t)stream);
+}
+
+int wsi_tile_gather(const uint8_t* slide, long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy,
+                    const float* lut, float* out_nchw, int n, int ph, int pw, void* stream) {
+    if (!slide || !tile_xy || !lut || !out_nchw) return WSI_EINVAL;
+    return wsi_tile_gather_dispatch(slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, out_nchw, n, ph, pw,
+                                    (hipStream_t)stream);
+}
+
+int wsi_stitch_add(const float* tile_logits, const int* map_xy, int t, int c, int dy, int dx, double* pred, int map_h,
+                   int map_w, void* stream) {
+    if (!tile_logits || !map_xy || !pred || map_h <= 0 || map_w <= 0) return WSI_EINVAL;
+    return wsi_stitch_add_dispatch(tile_logits, map_xy, t, c, dy, dx, pred, map_h, map_w, (hipStream_t)stream);
+}
+
+int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
+                                 uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream) {
+    if (!pred || !class_thresh) return WSI_EINVAL;
+    return wsi_softmax_dispatch(pred, c, hw, class_thresh, probs, classes, mask, heat_mode, heat, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ profiler
+// Optional HIP-event timing of every conv launch made by wsi_trunk_forward, on the stream the
+// kernels run on (bench.py's roofline leg).  Off by default; never active inside graph capture.
+#define WSI_PROF_MAX 4096
+static struct {
+    int enabled, count, cap;
+    hipEvent_t ev[2 * WSI_PROF_MAX];
+    int kind[WSI_PROF_MAX];
+    double flops[WSI_PROF_MAX];
+    int created;
+} g_prof;
+
+int wsi_prof_begin(int max_records) {
+    if (max_records <= 0 || max_records > WSI_PROF_MAX) return WSI_EINVAL;
+    for (; g_prof.created < 2 * max_records; ++g_prof.created)
+        if (hipEventCreate(&g_prof.ev[g_prof.created]) != hipSuccess) return WSI_ENOMEM;
+    g_prof.cap = max_records; g_prof.count = 0; g_prof.enabled = 1;
+    return WSI_OK;
+}
+
+int wsi_prof_end(float* ms_out, int* kind_out, double* flops_out, int cap) {
+    g_prof.enabled = 0;
+    int n = g_prof.count < cap ? g_prof.count : cap;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return WSI_EFAULT;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return WSI_EFAULT;
+        ms_out[i] = ms; kind_out[i] = g_prof.kind[i]; flops_out[i] = g_prof.flops[i];
+    }
+    g_prof.count = 0;
+    return n;
+}
+
+static inline int prof_open(hipStream_t st, int kind, double flops) {
+    if (!g_prof.enabled || g_prof.count >= g_prof.cap) return -1;
+    const int i = g_prof.count++;
+    g_prof.kind[i] = kind; g_prof.flops[i] = flops;
+    (void)hipEventRecord(g_prof.ev[2 * i], st);
+    return i;
+}
+static inline void prof_close(hipStream_t st, int i) { if (i >= 0) (void)hipEventRecord(g_prof.ev[2 * i + 1], st); }
+
+// ------------------------------------------------------------------------------------ trunk
+struct TrunkPlan {
+    size_t stem_scratch;          // byte offsets into the workspace
+    size_t buf[4][3];
+    size_t total;
+    int sh[4], sw[4], sc[4];
+};
+
+static int trunk_plan(int n, int h, int w, int planes, TrunkPlan& p) {
+    if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32 || planes < 1 || planes > 2) return WSI_EINVAL;
+    size_t off = 0;
+    p.stem_scratch = off;
+    off += align_up((size_t)n * (h / 2) * (w / 2) * 64 * sizeof(float), 256);
+    for (int s = 0; s < 4; ++s) {
+        p.sh[s] = h >> (2 + s); p.sw[s] = w >> (2 + s); p.sc[s] = 64 << s;
+        for (int b = 0; b < 3; ++b) {
+            p.buf[s][b] = off;
+            off += align_up(wsi_pf_bytes(n, p.sh[s], p.sw[s], p.sc[s], planes), 256);
+        }
+    }
+    p.total = off;
+    return WSI_OK;
+}
+
+size_t wsi_trunk_workspace_bytes(int n, int h, int w, int planes) {
+    TrunkPlan p;
+    return trunk_plan(n, h, w, planes, p) ? 0 : p.total;
+}
+
+int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, void* stream) {
+    TrunkPlan p;
+    if (!workspace || trunk_plan(n, h, w, planes, p)) return WSI_EINVAL;
+    return hipMemsetAsync((char*)workspace + p.buf[0][0], 0, p.total - p.buf[0][0], (hipStream_t)stream) == hipSuccess
+               ? WSI_OK
+               : WSI_EFAULT;
+}
+
+// Runs stem + residual stages; stops after stage `stop_after` (0 = pool, 1..8 = blocks, >= 8 all).
+// Returns the workspace offset / geometry of the last tensor produced.
+static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide, long long pitch, int slide_h,
+                     int slide_w, const int* tile_xy, const float* lut, int n, int h, int w, void* workspace,
+                     int stop_after, hipStream_t st, const TrunkPlan& p, size_t& last_off, int& last_stage) {
+    char* ws = (char*)workspace;
+    const int planes = wt->planes;
+    int rc;
+    {
+        const int pi_ = prof_open(st, 4, 2.0 * n * (h / 2) * (w / 2) * 64.0 * 147.0);
+        rc = wsi_stem_conv7x7_bn_relu_maxpool(in_f32, slide, pitch, slide_h, slide_w, tile_xy, lut, wt->stem_w, wt->stem_b, n,
+                                              h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0], planes, st);
+        prof_close(st, pi_);
+    }
+    if (rc) return rc;
+    last_off = p.buf[0][0]; last_stage = 0;
+    if (stop_after == 0) return WSI_OK;
+    // kind: 1 = 3x3 stride-1 (slab kernel), 2 = 3x3 stride-2 (gather), 3 = 1x1 downsample; flops = 2*M*N*K
+    // over real output pixels (padding taps counted)
+#define PROF_CONV(kind, HO, WO, CI, CO, KK, call)                                                    \
+    do {                                                                                            \
+        const int pi_ = prof_open(st, kind, 2.0 * n * (HO) * (WO) * (double)(CO) * (CI) * (KK));     \
+        rc = (call);                                                                                \
+        prof_close(st, pi_);                                                                        \
+    } while (0)
+    int cur = 0;                                       // index of the buffer holding the stage input
+    const void* x = ws + p.buf[0][0];
+    int block = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int H = p.sh[s], W = p.sw[s], C = p.sc[s];
+        for (int b = 0; b < 2; ++b) {
+            const int wi = s * 4 + b * 2;
+            void *mid, *out;
+            const void* resid;
+            if (s > 0 && b == 0) {                     // strided block with 1x1 downsample branch
+                mid = ws + p.buf[s][1];
+                void* ds = ws + p.buf[s][2];
+                out = ws + p.buf[s][0];
+                PROF_CONV(2, H, W, C / 2, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, 2 * H,
+                                                                  2 * W, C / 2, C, 2, 1, planes, st));
+                if (rc) return rc;
+                PROF_CONV(3, H, W, C / 2, C, 1, wsi_conv1x1_bn(x, ds, wt->down_w[s - 1], wt->down_b[s - 1], n, 2 * H, 2 * W,
+                                                              C / 2, C, 2, planes, st));
+                if (rc) return rc;
+                resid = ds;
+                cur = 0;
+                last_off = p.buf[s][0];
+            } else {
+                const int m = (cur + 1) % 3, o = (cur + 2) % 3;
+                mid = ws + p.buf[s][m];
+                out = ws + p.buf[s][o];
+                PROF_CONV(1, H, W, C, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, H, W, C, C,
+                                                              1, 1, planes, st));
+                if (rc) return rc;
+                resid = x;
+                cur = o;
+                last_off = p.buf[s][o];
+            }
+            PROF_CONV(1, H, W, C, C, 9, wsi_conv3x3_bn_act(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C,
+                                                          C, 1, 1, planes, st));
+            if (rc) return rc;
+            x = out;
+            ++block;
+            last_stage = s;
+            if (block == stop_after) return WSI_OK;
+        }
+    }
+    return WSI_OK;
+}
+
+int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
+                      long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                      int n, int h, int w, void* workspace, float* feat_out, float* logits_out, float* fmap_out,
+                      void* stream) {
+    TrunkPlan p;
+    if (!wt || !workspace || trunk_plan(n, h, w, wt->planes, p)) return WSI_EINVAL;
+    if (logits_out && (!wt->head_w || !wt->head_b || wt->head_k <= 0)) return WSI_EINVAL;
+    size_t off; int stage;
+    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, h, w, workspace, 8,
+                       (hipStream_t)stream, p, off, stage);
+    if (rc) return rc;
+    const char* last = (const char*)workspace + off;
+    if (feat_out || logits_out) {
+        rc = wsi_avgpool_fc(last, n, p.sh[3], p.sw[3], 512, wt->head_w, wt->head_b, wt->head_k, feat_out, logits_out,
+                            wt->planes, stream);
+        if (rc) return rc;
+    }
+    if (fmap_out) rc = wsi_pf_unpack(last, fmap_out, n, 512, p.sh[3], p.sw[3], wt->planes, stream);
+    return rc;
+}
+
+int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
+                          long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                          int n, int h, int w, void* workspace, int stop_after, float* tap_out_nchw, void* stream) {
+    TrunkPlan p;
+    if (!wt || !workspace || !tap_out_nchw || stop_after < 0 || stop_after > 8 || trunk_plan(n, h, w, wt->planes, p))
+        return WSI_EINVAL;
+    size_t off; int stage;
+    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, h, w, workspace,
+                       stop_after, (hipStream_t)stream, p, off, stage);
+    if (rc) return rc;
+    return wsi_pf_unpack((const char*)workspace + off, tap_out_nchw, n, p.sc[stage], p.sh[stage], p.sw[stage], wt->planes,
+                         stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// 3x3 / 1x1 convolution + folded BatchNorm + optional residual + ReLU on gfx950 MFMA.
+// Replaces the torch.nn ops of BasicBlock.forward (/root/reference/resnets_shift.py:49-65) and of
+// the downsample branch (resnets_shift.py:173-177) in eval mode.
+//
+// GEMM orientation: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]   (k = tap x cin)
+//   A operand = weights  (row = cout  = lane&31, 8 consecutive cin per lane half)
+//   B operand = pixels   (col = pixel = lane&31, the same 8 cin)
+// so an accumulator register group holds 4 consecutive output channels of ONE pixel and the
+// epilogue stores 8-byte channel runs into the pixel's 128-byte line.
+//
+// Precision: PLANES=2 multiplies bf16 hi/lo splits in three MFMA passes (hi*hi + hi*lo + lo*hi,
+// fp32 accumulate): ~2^-16 relative operand error, needed for the 1e-3 logit contract
+// (single-pass bf16 is 1.9e-2 off).  PLANES=1 is the single-pass bf16
+// speed mode.
+#include "common.h"
+
+// --------------------------------------------------------------------------------------------
+// Fused epilogue: bias (+ residual) (+ ReLU), split to bf16 planes, store.  acc[mt] covers
+// pixels q_base + mt*32 + (lane&31) and channels ntile*32 + 8g + 4h + i.
+template <int MT, int PLANES>
+static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT], int q_base, int ntile,
+                                                     int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const size_t pixstride = (size_t)a.go.C * PLANES * 2;
+    float bias[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = q_base + mt * 32 + l31;
+        if (!pf_is_pixel(a.go, q)) continue;
+        char* opix = (char*)a.out + (size_t)q * pixstride + (size_t)ntile * (64 * PLANES);
+        const char* rpix = a.resid ? (const char*)a.resid + (size_t)q * pixstride + (size_t)ntile * (64 * PLANES) : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int coff = (8 * g + 4 * h) * 2;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[mt][4 * g + i] + bias[4 * g + i];
+            if (rpix) {
+                bf16x4 rh = *(const bf16x4*)(rpix + coff);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += (float)rh[i];
+                if constexpr (PLANES == 2) {
+                    bf16x4 rl = *(const bf16x4*)(rpix + 64 + coff);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hi[i] = (__bf16)v[i];
+                lo[i] = (__bf16)(v[i] - (float)hi[i]);
+            }
+            *(bf16x4*)(opix + coff) = hi;
+            if constexpr (PLANES == 2) *(bf16x4*)(opix + 64 + coff) = lo;
+        }
+    }
+}
+
+// One 128-byte line of K for MT pixel tiles: 4 fragments per operand.
+template <int MT, int PLANES>
+static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8 (&wf)[4], const char* smem,
+                                                 const int (&xbase)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 xf[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xf[f] = *(const bf16x8*)(smem + (xbase[mt] ^ (f << 5)));
+        if constexpr (PLANES == 2) {
+            acc[mt] = mfma_bf16(wf[2], xf[0], acc[mt]);   // lo*hi
+            acc[mt] = mfma_bf16(wf[3], xf[1], acc[mt]);
+            acc[mt] = mfma_bf16(wf[0], xf[2], acc[mt]);   // hi*lo
+            acc[mt] = mfma_bf16(wf[1], xf[3], acc[mt]);
+            acc[mt] = mfma_bf16(wf[0], xf[0], acc[mt]);   // hi*hi
+            acc[mt] = mfma_bf16(wf[1], xf[1], acc[mt]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(wf[f], xf[f], acc[mt]);
+        }
+    }
+}
+
+// LDS byte offset of slot-pair base for slab-local pixel Pl and lane half h (swizzled):
+// slot s = 2f + h is stored at slot s ^ ((Pl>>1)&7); fragment f is reached by XOR (f<<5).
+static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128 + ((h ^ ((Pl >> 1) & 7)) << 4); }
+
+// --------------------------------------------------------------------------------------------
+// Stride-1 3x3: the input pixels a tile of BM consecutive PF positions needs form ONE contiguous
+// range [q0-P-1, q0+BM+P+1): stage that slab once per 128-byte line, then all nine taps are LDS
+// address shifts.  Wave (wm, wn) computes pixels [wm*MT*32, +MT*32) x couts [32*(nb*WN+wn), +32).
+template <int MT, int WM, int WN, int PLANES>
+__global__ __launch_bounds__(WM* WN * 64) void conv3x3s1_slab_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MT * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    const int nb = blockIdx.x % nblocks;
+    const int mtile = blockIdx.x / nblocks;
+    const int P = a.gi.P;
+    const int q0 = a.gi.G + mtile * BM;
+    const int slab_px = BM + 2 * P + 2;
+    const int ntile = nb * WN + wn;
+    const int NC = a.gi.C * PLANES / 64;
+    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
+    const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * 9 * 4 * 64 + lane;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    for (int c = 0; c < NC; ++c) {
+        if (c) __syncthreads();
+        for (int i = tid; i < slab_px * 8; i += NTHREADS) {
+            const int Pl = i >> 3, sp = i & 7;
+            const int s = sp ^ ((Pl >> 1) & 7);
+            *(uint4*)(smem + (size_t)i * 16) = *(const uint4*)(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16);
+        }
+        __syncthreads();
+        const bf16x8* wp = wbase + (size_t)c * 9 * 4 * 64;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            bf16x8 wf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = wp[(t * 4 + f) * 64];
+            const int toff = (t / 3 - 1) * P + (t % 3 - 1) + P + 1;
+            int xbase[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(wm * MT * 32 + mt * 32 + l31 + toff, h);
+            mfma_line<MT, PLANES>(acc, wf, smem, xbase);
+        }
+    }
+    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+}
+
+// --------------------------------------------------------------------------------------------
+// Generic gather kernel (3x3 stride 2, 1x1 stride 2, also stride 1): per (line, tap) step the BM
+// input pixels are gathered into an LDS tile by per-lane source addresses.  Pad output positions
+// gather pixel 0 (always a zero guard) and are dropped by the epilogue.
+template <int MT, int WM, int WN, int PLANES>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MT * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int PPT = BM * 8 / NTHREADS;          // 16-byte pieces per thread per step
+    constexpr int PIX_STEP = NTHREADS / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    const int nb = blockIdx.x % nblocks;
+    const int mtile = blockIdx.x / nblocks;
+    const int q0 = a.go.G + mtile * BM;
+    const int ntile = nb * WN + wn;
+    const int NC = a.gi.C * PLANES / 64;
+    const int KS = a.ksize, NT = KS * KS, pad = KS / 2;
+    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * NT * 4 * 64 + lane;
+
+    // input pixel (tap 0,0) of each output pixel this thread stages
+    int inq[PPT];
+    const int sp = tid & 7;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int m = (tid >> 3) + k * PIX_STEP;
+        const int q = q0 + m;
+        int r = q - a.go.G;
+        int v = -1;
+        if (r >= 0 && r < a.go.NS) {
+            const int n = r / a.go.S;
+            r -= n * a.go.S;
+            const int y = r / a.go.P, x = r - y * a.go.P;
+            if (x != a.go.W && y != a.go.H)
+                v = a.gi.G + n * a.gi.S + (y * a.stride - pad) * a.gi.P + (x * a.stride - pad);
+        }
+        inq[k] = v;
+    }
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    int xbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(wm * MT * 32 + mt * 32 + l31, h);
+
+    for (int c = 0; c < NC; ++c) {
+        for (int t = 0; t < NT; ++t) {
+            const int toff = (t / KS) * a.gi.P + (t % KS);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int m = (tid >> 3) + k * PIX_STEP;
+                const int s = sp ^ ((m >> 1) & 7);
+                const int src = inq[k] < 0 ? 0 : inq[k] + toff;
+                *(uint4*)(smem + (size_t)(m * 8 + sp) * 16) =
+                    *(const uint4*)((const char*)a.in + (size_t)src * in_pixstride + c * 128 + s * 16);
+            }
+            bf16x8 wf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wf[f] = wbase[((size_t)(c * NT + t) * 4 + f) * 64];
+            __syncthreads();
+            mfma_line<MT, PLANES>(acc, wf, smem, xbase);
+        }
+    }
+    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+}
+
+// --------------------------------------------------------------------------------------------
+template <int MT, int WM, int WN, int PLANES>
+static int launch_slab(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MT * 32;
+    const int mtiles = (a.gi.NS + BM - 1) / BM;
+    const int nblocks = a.go.C / (WN * 32);
+    const size_t lds = (size_t)(BM + 2 * a.gi.P + 2) * 128;
+    if (lds > 160 * 1024) return WSI_EINVAL;
+    auto k = conv3x3s1_slab_kernel<MT, WM, WN, PLANES>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return WSI_EINVAL;
+    }
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(WM * WN * 64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+template <int MT, int WM, int WN, int PLANES>
+static int launch_gather(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MT * 32;
+    const int mtiles = (a.go.NS + BM - 1) / BM;
+    const int nblocks = a.go.C / (WN * 32);
+    const size_t lds = (size_t)BM * 128;
+    hipLaunchKernelGGL((conv_gather_kernel<MT, WM, WN, PLANES>), dim3(mtiles * nblocks), dim3(WM * WN * 64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+// Host dispatch.  Tile shapes: every wave owns 32 output channels (weights stay in its
+// registers for a whole tap) and MT*32 pixels; WN waves share one pixel slab.
+int wsi_conv_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
+    const int cout = a.go.C;
+    if (a.gi.C % 64 || cout % 64 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    if (a.ksize == 3 && a.stride == 1) {
+        if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;
+        if (cout % 128 == 0) return planes == 2 ? launch_slab<8, 1, 4, 2>(a, st) : launch_slab<8, 1, 4, 1>(a, st);
+        return planes == 2 ? launch_slab<4, 2, 2, 2>(a, st) : launch_slab<4, 2, 2, 1>(a, st);
+    }
+    if ((a.ksize == 3 || a.ksize == 1) && (a.stride == 1 || a.stride == 2)) {
+        if (a.go.H * a.stride != a.gi.H || a.go.W * a.stride != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
+        if (cout % 128 == 0) return planes == 2 ? launch_gather<8, 1, 4, 2>(a, st) : launch_gather<8, 1, 4, 1>(a, st);
+        return planes == 2 ? launch_gather<4, 2, 2, 2>(a, st) : launch_gather<4, 2, 2, 1>(a, st);
+    }
+    return WSI_EINVAL;
+}

@@ -1,0 +1,173 @@
+// Heads and layout converters.
+//   avgpool_fc : AdaptiveAvgPool2d((1,1)) + flatten + Linear(F -> K)
+//                (/root/reference/resnets_shift.py:206-208 `fc0`; /root/reference/models/models.py:32-38 Classifier)
+//   linear     : y = act(x W^T + b), fp32 (/root/reference/resnets_shift.py:135-139,215 `fc`;
+//                /root/reference/models/models.py:46-50 Regressor)
+//   pf_pack / pf_unpack : f32 NCHW <-> padded-flat bf16 planes (API boundary + tests)
+#include "common.h"
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One workgroup per image. feat[n][c] = mean over H*W of (hi+lo); logits[n][k] = feat . w[k] + b[k].
+template <int PLANES>
+__global__ __launch_bounds__(256) void avgpool_fc_kernel(const void* in, PFGeom g, const float* w, const float* b, int K,
+                                                         float* feat, float* logits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* f = (float*)smem;                            // C floats
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const size_t pixstride = (size_t)g.C * PLANES * 2;
+    const float inv = 1.0f / (float)(g.H * g.W);
+    for (int c4 = tid; c4 < g.C / 4; c4 += 256) {
+        const int c = c4 * 4;
+        const size_t coff = PLANES == 2 ? (size_t)(c >> 5) * 128 + (c & 31) * 2 : (size_t)c * 2;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < g.H; ++y)
+            for (int x = 0; x < g.W; ++x) {
+                const char* p = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * pixstride + coff;
+                const bf16x4 hi = *(const bf16x4*)p;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += (float)hi[k];
+                if constexpr (PLANES == 2) {
+                    const bf16x4 lo = *(const bf16x4*)(p + 64);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] += (float)lo[k];
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[c + k] = s[k] * inv;
+            if (feat) feat[(size_t)n * g.C + c + k] = s[k] * inv;
+        }
+    }
+    __syncthreads();
+    if (!logits) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = wave; k < K; k += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < g.C; c += 64) acc += f[c] * w[(size_t)k * g.C + c];
+        acc = wave_sum(acc);
+        if (lane == 0) logits[(size_t)n * K + k] = acc + b[k];
+    }
+}
+
+// y[b][j] = act(sum_k x[b][k] * w[j][k] + bias[j]).  One wave per output j, up to BT rows of x per
+// pass (weights are streamed once per pass, coalesced 16 B per lane).
+template <int BT>
+__global__ __launch_bounds__(256) void linear_kernel(const float* x, const float* w, const float* bias, float* y, int B,
+                                                     int K, int J, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= J) return;
+    const f32x4* wr = (const f32x4*)(w + (size_t)j * K);
+    for (int b0 = 0; b0 < B; b0 += BT) {
+        float acc[BT];
+#pragma unroll
+        for (int t = 0; t < BT; ++t) acc[t] = 0.f;
+        for (int k4 = lane; k4 < K / 4; k4 += 64) {
+            const f32x4 wv = wr[k4];
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                if (b0 + t < B) {
+                    const f32x4 xv = ((const f32x4*)(x + (size_t)(b0 + t) * K))[k4];
+                    acc[t] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            const float s = wave_sum(acc[t]);
+            if (lane == 0 && b0 + t < B) {
+                float v = s + (bias ? bias[j] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)(b0 + t) * J + j] = v;
+            }
+        }
+    }
+}
+
+template <int PLANES>
+__global__ __launch_bounds__(256) void pf_pack_kernel(const float* in, void* out, PFGeom g) {
+    const long long total = (long long)g.N * g.H * g.W * g.C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        long long p = i / g.C;
+        const int x = (int)(p % g.W); p /= g.W;
+        const int y = (int)(p % g.H);
+        const int n = (int)(p / g.H);
+        const float v = in[(((size_t)n * g.C + c) * g.H + y) * g.W + x];
+        __bf16 hi, lo;
+        split_bf16(v, hi, lo);
+        char* o = (char*)out + (size_t)(g.G + n * g.S + y * g.P + x) * ((size_t)g.C * PLANES * 2);
+        if constexpr (PLANES == 2) {
+            *(__bf16*)(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
+            *(__bf16*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
+        } else {
+            *(__bf16*)(o + c * 2) = hi;
+        }
+    }
+}
+
+template <int PLANES>
+__global__ __launch_bounds__(256) void pf_unpack_kernel(const void* in, float* out, PFGeom g) {
+    const long long total = (long long)g.N * g.H * g.W * g.C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        long long p = i / g.C;
+        const int x = (int)(p % g.W); p /= g.W;
+        const int y = (int)(p % g.H);
+        const int n = (int)(p / g.H);
+        const char* o = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * ((size_t)g.C * PLANES * 2);
+        float v;
+        if constexpr (PLANES == 2)
+            v = (float)*(const __bf16*)(o + (c >> 5) * 128 + (c & 31) * 2) +
+                (float)*(const __bf16*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2);
+        else
+            v = (float)*(const __bf16*)(o + c * 2);
+        out[(((size_t)n * g.C + c) * g.H + y) * g.W + x] = v;
+    }
+}
+
+static int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
+                            float* logits, int planes, hipStream_t st) {
+    if (g.C % 4 || g.N <= 0 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    const size_t lds = (size_t)g.C * 4;
+    if (planes == 2)
+        hipLaunchKernelGGL(avgpool_fc_kernel<2>, dim3(g.N), dim3(256), lds, st, in, g, w, b, K, feat, logits);
+    else
+        hipLaunchKernelGGL(avgpool_fc_kernel<1>, dim3(g.N), dim3(256), lds, st, in, g, w, b, K, feat, logits);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
+                        hipStream_t st) {
+    if (K % 4 || B <= 0 || J <= 0) return WSI_EINVAL;
+    hipLaunchKernelGGL(linear_kernel<8>, dim3((J + 3) / 4), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_pf_pack_dispatch(const float* in, void* out, const PFGeom& g, int planes, hipStream_t st) {
+    const long long total = (long long)g.N * g.H * g.W * g.C;
+    if (planes == 2)
+        hipLaunchKernelGGL(pf_pack_kernel<2>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
+    else
+        hipLaunchKernelGGL(pf_pack_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_pf_unpack_dispatch(const void* in, float* out, const PFGeom& g, int planes, hipStream_t st) {
+    const long long total = (long long)g.N * g.H * g.W * g.C;
+    if (planes == 2)
+        hipLaunchKernelGGL(pf_unpack_kernel<2>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
+    else
+        hipLaunchKernelGGL(pf_unpack_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}

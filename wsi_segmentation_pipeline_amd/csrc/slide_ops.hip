@@ -1,0 +1,105 @@
+// Slide-side kernels of the sliding-window driver.
+//   tile_gather   : u8 slide + tile corners -> normalised f32 NCHW batch
+//                   (/root/reference/utils/dataset.py:171-185 + utils/preprocessing.py:209-212)
+//   stitch_add    : pred[:, ty:ty+dy, tx:tx+dx] += tile_logits  in float64
+//                   (/root/reference/utils/eval.py:213-215; also :58-60 with per-pixel tiles)
+//   softmax_threshold_argmax : /root/reference/utils/preprocessing.py:156-172 (+ heat map of
+//                   /root/reference/utils/eval.py:219-228)
+#include "common.h"
+
+__global__ __launch_bounds__(256) void tile_gather_kernel(const uint8_t* slide, long long pitch, int SH, int SW,
+                                                          const int* origins, const float* lut, float* out, int N,
+                                                          int ph, int pw) {
+    const long long total = (long long)N * ph * pw;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % pw);
+        long long p = i / pw;
+        const int y = (int)(p % ph);
+        const int n = (int)(p / ph);
+        const int sx = origins[2 * n] + x, sy = origins[2 * n + 1] + y;
+        uint8_t px[3] = {0, 0, 0};
+        if (sx >= 0 && sx < SW && sy >= 0 && sy < SH) {
+            const uint8_t* s = slide + (size_t)sy * pitch + (size_t)sx * 3;
+            px[0] = s[0]; px[1] = s[1]; px[2] = s[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(((size_t)n * 3 + c) * ph + y) * pw + x] = lut[c * 256 + px[c]];
+    }
+}
+
+// One thread per (tile, footprint pixel); every class of that pixel is added by the same thread.
+// Sums of <= a few dozen fp32 logits are exact in float64, so the atomic order cannot change
+// the result (the reference's shuffled DataLoader order does not either).
+__global__ __launch_bounds__(256) void stitch_add_kernel(const float* logits, const int* txy, int T, int C, int dy, int dx,
+                                                         double* pred, int MH, int MW) {
+    const long long total = (long long)T * dy * dx;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int fx = (int)(i % dx);
+        long long p = i / dx;
+        const int fy = (int)(p % dy);
+        const int t = (int)(p / dy);
+        const int x = txy[2 * t] + fx, y = txy[2 * t + 1] + fy;
+        if (x < 0 || x >= MW || y < 0 || y >= MH) continue;       // numpy slice clipping
+        for (int c = 0; c < C; ++c)
+            atomicAdd(pred + ((size_t)c * MH + y) * MW + x, (double)logits[(size_t)t * C + c]);
+    }
+}
+
+#define WSI_MAX_CLASSES 16
+__global__ __launch_bounds__(256) void softmax_threshold_argmax_kernel(const double* pred, int C, long long HW,
+                                                                       const double* thresh, double* probs,
+                                                                       uint8_t* classes, const uint8_t* mask,
+                                                                       int heat_mode, uint8_t* heat) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+        double v[WSI_MAX_CLASSES];
+        double mx = pred[i];
+        for (int c = 0; c < C; ++c) { v[c] = pred[(size_t)c * HW + i]; mx = v[c] > mx ? v[c] : mx; }
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) { v[c] = exp(v[c] - mx); s += v[c]; }
+        int best = 0;
+        double bv = -1.0;
+        for (int c = 0; c < C; ++c) {
+            double p = v[c] / s;
+            if (p < thresh[c]) p = 0.0;
+            v[c] = p;
+            if (probs) probs[(size_t)c * HW + i] = p;
+            if (p > bv) { bv = p; best = c; }                      // first maximum, like np.argmax
+        }
+        if (classes) classes[i] = (uint8_t)best;
+        if (heat) {
+            double hv = heat_mode == 0 ? v[1] : v[2] + v[3];
+            hv *= (double)(mask ? mask[i] : 1);
+            heat[i] = (uint8_t)(int)(255.0 * hv);                  // np.uint8() truncation
+        }
+    }
+}
+
+static int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+int wsi_tile_gather_dispatch(const uint8_t* slide, long long pitch, int SH, int SW, const int* origins, const float* lut,
+                             float* out, int N, int ph, int pw, hipStream_t st) {
+    if (N <= 0 || ph <= 0 || pw <= 0) return WSI_EINVAL;
+    hipLaunchKernelGGL(tile_gather_kernel, dim3(grid_for((long long)N * ph * pw)), dim3(256), 0, st, slide, pitch, SH, SW,
+                       origins, lut, out, N, ph, pw);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_stitch_add_dispatch(const float* logits, const int* txy, int T, int C, int dy, int dx, double* pred, int MH, int MW,
+                            hipStream_t st) {
+    if (T <= 0 || C <= 0 || dy <= 0 || dx <= 0) return WSI_EINVAL;
+    hipLaunchKernelGGL(stitch_add_kernel, dim3(grid_for((long long)T * dy * dx)), dim3(256), 0, st, logits, txy, T, C, dy, dx,
+                       pred, MH, MW);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
+                         const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st) {
+    if (C <= 0 || C > WSI_MAX_CLASSES || HW <= 0) return WSI_EINVAL;
+    if (heat && ((heat_mode == 0 && C < 2) || (heat_mode == 1 && C < 4))) return WSI_EINVAL;
+    hipLaunchKernelGGL(softmax_threshold_argmax_kernel, dim3(grid_for(HW)), dim3(256), 0, st, pred, C, HW, thresh, probs,
+                       classes, mask, heat_mode, heat);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}

@@ -1,0 +1,198 @@
+// Stem: (tile fetch +) colour normalisation + conv 7x7 stride 2 pad 3 (3->64) + folded BN + ReLU on
+// MFMA, then maxpool 3x3 stride 2 pad 1 into the padded-flat layout.
+// Replaces /root/reference/resnets_shift.py:196-199 (conv1, bn1, relu, maxpool) together with the
+// eval transform /root/reference/utils/preprocessing.py:209-212 (ToTensor + Normalize) and the tile
+// read /root/reference/utils/dataset.py:174-178 when the input is a u8 slide.
+//
+// K ordering for the MFMA: k = kh*32 + kw*4 + c with kw padded 7->8 and c padded 3->4 (zero
+// weights), so K = 224 = 14 k-steps of 16 and a lane's 8 consecutive k are two neighbouring input
+// pixels (4 channels each) = one aligned 16-byte LDS read of the [row][col][4ch] bf16 image.
+#include "common.h"
+
+constexpr int STEM_TR = 8;                       // conv-output rows per tile
+constexpr int STEM_TC = 32;                      // conv-output cols per tile
+constexpr int STEM_LR = 2 * STEM_TR + 5;         // 21 input rows
+constexpr int STEM_LC = 70;                      // 2*32 + 6 input cols
+constexpr int STEM_PLANE_BYTES = STEM_LR * STEM_LC * 8;
+
+template <int PLANES>
+__global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;                                  // weights: 28*PLANES KiB
+    char* xl = smem + 28 * PLANES * 1024;             // input image planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Hc = a.H / 2, Wc = a.W / 2;
+    const int tiles_x = (Wc + STEM_TC - 1) / STEM_TC, tiles_y = Hc / STEM_TR;
+    const int total = a.N * tiles_x * tiles_y;
+
+    for (int i = tid; i < 28 * PLANES * 64; i += 256) ((uint4*)wl)[i] = ((const uint4*)a.wpk)[i];
+
+    float bias[2][16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[nt][r] = a.bias[nt * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
+
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        const int oy0 = (trem / tiles_x) * STEM_TR, ox0 = (trem % tiles_x) * STEM_TC;
+        __syncthreads();                              // previous tile's readers done (and weights landed)
+        // ---- stage the normalised input patch as bf16 (hi, lo) [row][col][4] ------------------
+        int tx = 0, ty = 0;
+        if (a.mode == 1) { tx = a.origins[2 * n]; ty = a.origins[2 * n + 1]; }
+        for (int i = tid; i < STEM_LR * STEM_LC; i += 256) {
+            const int r = i / STEM_LC, cc = i - r * STEM_LC;
+            const int iy = 2 * oy0 - 3 + r, ix = 2 * ox0 - 3 + cc;
+            float v[3] = {0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                if (a.mode == 0) {
+                    const size_t base = ((size_t)n * 3 * a.H + iy) * a.W + ix;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = a.in_f32[base + (size_t)c * a.H * a.W];
+                } else {
+                    const int sx = tx + ix, sy = ty + iy;
+                    uint8_t px[3] = {0, 0, 0};       // outside the slide OpenSlide pads with black
+                    if (sx >= 0 && sx < a.SW && sy >= 0 && sy < a.SH) {
+                        const uint8_t* p = a.slide + (size_t)sy * a.slide_pitch + (size_t)sx * 3;
+                        px[0] = p[0]; px[1] = p[1]; px[2] = p[2];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = a.lut[c * 256 + px[c]];
+                }
+            }
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { hi[c] = (__bf16)v[c]; lo[c] = (__bf16)(v[c] - (float)hi[c]); }
+            hi[3] = (__bf16)0.f; lo[3] = (__bf16)0.f;
+            *(bf16x4*)(xl + (size_t)i * 8) = hi;
+            if constexpr (PLANES == 2) *(bf16x4*)(xl + STEM_PLANE_BYTES + (size_t)i * 8) = lo;
+        }
+        __syncthreads();
+
+        f32x16 acc[2][2];                             // [nt][mt]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+
+#pragma unroll 2
+        for (int s = 0; s < 14; ++s) {
+            const int kh = s >> 1, kw0 = (s & 1) * 4 + 2 * h;
+            bf16x8 wf[2][PLANES], xf[2][PLANES];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int p = 0; p < PLANES; ++p)
+                    wf[nt][p] = *(const bf16x8*)(wl + ((size_t)((nt * 14 + s) * PLANES + p) * 64 + lane) * 16);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = 2 * (2 * wave + mt) + kh, col = 2 * l31 + kw0;
+#pragma unroll
+                for (int p = 0; p < PLANES; ++p)
+                    xf[mt][p] = *(const bf16x8*)(xl + p * STEM_PLANE_BYTES + (size_t)(row * STEM_LC + col) * 8);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    if constexpr (PLANES == 2) {
+                        acc[nt][mt] = mfma_bf16(wf[nt][1], xf[mt][0], acc[nt][mt]);
+                        acc[nt][mt] = mfma_bf16(wf[nt][0], xf[mt][1], acc[nt][mt]);
+                    }
+                    acc[nt][mt] = mfma_bf16(wf[nt][0], xf[mt][0], acc[nt][mt]);
+                }
+        }
+        // ---- epilogue: bias + ReLU -> f32 NHWC -------------------------------------------------
+        const int ox = ox0 + l31;
+        if (ox < Wc) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int oy = oy0 + 2 * wave + mt;
+                float* o = a.out + (((size_t)n * Hc + oy) * Wc + ox) * 64;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[nt][mt][4 * g + i] + bias[nt][4 * g + i], 0.f);
+                        *(f32x4*)(o + nt * 32 + 8 * g + 4 * h) = v;
+                    }
+            }
+        }
+    }
+}
+
+// maxpool 3x3 s2 p1 over f32 NHWC [N][Hc][Wc][64] -> PF activations (Hc/2 x Wc/2 x 64).
+// One thread = one output pixel x 4 channels.
+template <int PLANES>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* in, void* out, int N, int Hc, int Wc, PFGeom go) {
+    const long long total = (long long)N * go.H * go.W * 16;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        long long p = i >> 4;
+        const int px = (int)(p % go.W); p /= go.W;
+        const int py = (int)(p % go.H);
+        const int n = (int)(p / go.H);
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};                  // inputs are post-ReLU (>= 0): 0 == -inf padding
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = 2 * py + dy;
+            if (y < 0 || y >= Hc) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = 2 * px + dx;
+                if (x < 0 || x >= Wc) continue;
+                const f32x4 v = *(const f32x4*)(in + (((size_t)n * Hc + y) * Wc + x) * 64 + c4 * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        }
+        const int q = go.G + n * go.S + py * go.P + px;
+        const int c = c4 * 4;
+        char* o = (char*)out + (size_t)q * (64 * PLANES * 2);
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hi[k] = (__bf16)m[k]; lo[k] = (__bf16)(m[k] - (float)hi[k]); }
+        if constexpr (PLANES == 2) {
+            *(bf16x4*)(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
+            *(bf16x4*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
+        } else {
+            *(bf16x4*)(o + c * 2) = hi;
+        }
+    }
+}
+
+int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st) {
+    if (a.H % 16 || a.W % 2 || a.N <= 0 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    const int Hc = a.H / 2, Wc = a.W / 2;
+    const int total = a.N * ((Wc + STEM_TC - 1) / STEM_TC) * (Hc / STEM_TR);
+    const int grid = total < 2048 ? total : 2048;
+    const size_t lds = (size_t)28 * planes * 1024 + (size_t)planes * STEM_PLANE_BYTES;
+    if (planes == 2) {
+        auto k = stem_conv7x7_kernel<2>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return WSI_EINVAL;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(stem_conv7x7_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st) {
+    if (Hc % 2 || Wc % 2) return WSI_EINVAL;
+    PFGeom go = pf_geom(N, Hc / 2, Wc / 2, 64);
+    const long long total = (long long)N * go.H * go.W * 16;
+    long long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (planes == 2)
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<2>, dim3((int)grid), dim3(256), 0, st, in, out, N, Hc, Wc, go);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<1>, dim3((int)grid), dim3(256), 0, st, in, out, N, Hc, Wc, go);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}

@@ -1,0 +1,312 @@
+"""Host side of the HIP inference path: weight prepack, workspaces and launch wrappers.
+
+PyTorch is used only as plumbing (device memory, streams); all compute goes through
+libwsi_hip.so (include/wsi_hip.h).  There is no CPU fallback: tensors must live on a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import native
+
+BN_EPS = 1e-5                                   # nn.BatchNorm2d default (reference resnets_shift.py:117)
+PARITY, SPEED = 2, 1                            # planes: bf16x2 split (3 MFMA passes) / single bf16
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(sd, key):
+    return np.ascontiguousarray(sd[key].detach().to('cpu', torch.float32).numpy())
+
+
+def normalize_lut(mean, std):
+    """3x256 fp32 table of the eval transform (reference utils/preprocessing.py:209-212)."""
+    lib = native.load()
+    m = np.asarray(mean, np.float32)
+    s = np.asarray(std, np.float32)
+    out = np.empty((3, 256), np.float32)
+    native.check(lib.wsi_normalize_u8_lut(_np_ptr(m), _np_ptr(s), _np_ptr(out)), 'wsi_normalize_u8_lut')
+    return out
+
+
+def _require_gpu(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a GPU tensor: the WSI inference path runs on HIP kernels only '
+                           '(no CPU fallback)' % what)
+
+
+class TrunkEngine:
+    """ResNet-18 trunk (stem + layer1..4) of the reference ``resnets_shift.ResNet`` on HIP kernels,
+    with an optional Linear(512->K) head fused after the average pool (``fc0`` or ``Classifier``).
+
+    state_dict: reference key names (conv1.weight, bn1.*, layerL.B.convK.weight, ...).
+    """
+
+    def __init__(self, state_dict, device, planes=PARITY, head=None, max_batch=256,
+                 mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        self.lib = native.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('TrunkEngine needs a GPU device, got %s' % device)
+        if planes not in (1, 2):
+            raise ValueError('planes must be 1 (speed) or 2 (parity)')
+        self.planes = planes
+        self.max_batch = int(max_batch)
+        self._keep = []                          # device tensors referenced by raw pointers
+        self._ws = {}
+        self.wt = native.WsiTrunkWeights()
+        self.wt.planes = planes
+        sd = state_dict
+
+        def bn(prefix):
+            return [_f32(sd, prefix + s) for s in ('.weight', '.bias', '.running_mean', '.running_var')]
+
+        def dev(a):
+            t = torch.from_numpy(a).to(self.device)
+            self._keep.append(t)
+            return t
+
+        # stem
+        w = _f32(sd, 'conv1.weight')
+        pk = np.empty(self.lib.wsi_prepack_stem_bytes(planes), np.uint8)
+        bias = np.empty(64, np.float32)
+        g, b, m, v = bn('bn1')
+        native.check(self.lib.wsi_prepack_stem(_np_ptr(w), _np_ptr(g), _np_ptr(b), _np_ptr(m), _np_ptr(v), BN_EPS,
+                                               planes, _np_ptr(pk), _np_ptr(bias)), 'wsi_prepack_stem')
+        self.wt.stem_w = dev(pk).data_ptr()
+        self.wt.stem_b = dev(bias).data_ptr()
+
+        def conv(wkey, bnkey, k):
+            w = _f32(sd, wkey)
+            cout, cin = w.shape[0], w.shape[1]
+            pk = np.empty(self.lib.wsi_prepack_conv_bytes(cout, cin, k, planes), np.uint8)
+            bias = np.empty(cout, np.float32)
+            g, b, m, v = bn(bnkey)
+            native.check(self.lib.wsi_prepack_conv(_np_ptr(w), _np_ptr(g), _np_ptr(b), _np_ptr(m), _np_ptr(v), BN_EPS,
+                                                   cout, cin, k, planes, _np_ptr(pk), _np_ptr(bias)), 'wsi_prepack_conv')
+            return dev(pk).data_ptr(), dev(bias).data_ptr()
+
+        for L in range(1, 5):
+            for B in range(2):
+                for K in (1, 2):
+                    p = 'layer%d.%d' % (L, B)
+                    i = (L - 1) * 4 + B * 2 + (K - 1)
+                    self.wt.conv_w[i], self.wt.conv_b[i] = conv('%s.conv%d.weight' % (p, K), '%s.bn%d' % (p, K), 3)
+            if L > 1:
+                p = 'layer%d.0.downsample' % L
+                self.wt.down_w[L - 2], self.wt.down_b[L - 2] = conv(p + '.0.weight', p + '.1', 1)
+        self.set_head(head)
+        self.lut = dev(normalize_lut(mean, std))
+
+    # ------------------------------------------------------------------ configuration
+    def set_head(self, head):
+        """head = (weight (K,512), bias (K,)) tensors/arrays or None."""
+        if head is None:
+            self.wt.head_w, self.wt.head_b, self.wt.head_k = None, None, 0
+            self.head_k = 0
+            return
+        w = torch.as_tensor(head[0]).detach().to(self.device, torch.float32).contiguous()
+        b = torch.as_tensor(head[1]).detach().to(self.device, torch.float32).contiguous()
+        if w.dim() != 2 or w.shape[1] != 512 or b.shape[0] != w.shape[0]:
+            raise ValueError('head must be Linear(512 -> K)')
+        self._head = (w, b)
+        self.wt.head_w, self.wt.head_b, self.wt.head_k = w.data_ptr(), b.data_ptr(), int(w.shape[0])
+        self.head_k = int(w.shape[0])
+
+    def _workspace(self, n, h, w):
+        key = (n, h, w)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.wsi_trunk_workspace_bytes(n, h, w, self.planes)
+            if nbytes == 0:
+                raise ValueError('unsupported patch shape %dx%d (need multiples of 32) or batch %d' % (h, w, n))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            native.check(self.lib.wsi_trunk_workspace_init(_ptr(ws), n, h, w, self.planes, _stream()),
+                         'wsi_trunk_workspace_init')
+            if len(self._ws) >= 4:                    # keep the plan cache small
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward passes
+    def _run(self, n, h, w, in_f32, slide, tile_xy, want_feat, want_logits, want_fmap, tap=None):
+        ws = self._workspace(n, h, w)
+        dev = self.device
+        feat = torch.empty((n, 512), dtype=torch.float32, device=dev) if want_feat else None
+        logits = torch.empty((n, self.head_k), dtype=torch.float32, device=dev) if want_logits else None
+        fmap = torch.empty((n, 512, h // 32, w // 32), dtype=torch.float32, device=dev) if want_fmap else None
+        if slide is not None:
+            sp, pitch, sh, sw = _ptr(slide), slide.stride(0), slide.shape[0], slide.shape[1]
+        else:
+            sp, pitch, sh, sw = None, 0, 0, 0
+        if tap is not None:
+            stage = (0, 1, 1, 2, 2, 3, 3, 4, 4)[tap]
+            c = 64 << max(stage - 1, 0)
+            hh = h >> (2 + max(stage - 1, 0))
+            ww = w >> (2 + max(stage - 1, 0))
+            out = torch.empty((n, c, hh, ww), dtype=torch.float32, device=dev)
+            native.check(self.lib.wsi_trunk_forward_tap(C.byref(self.wt), _ptr(in_f32), sp, pitch, sh, sw, _ptr(tile_xy),
+                                                        _ptr(self.lut), n, h, w, _ptr(ws), tap, _ptr(out), _stream()),
+                         'wsi_trunk_forward_tap')
+            return out
+        native.check(self.lib.wsi_trunk_forward(C.byref(self.wt), _ptr(in_f32), sp, pitch, sh, sw, _ptr(tile_xy),
+                                                _ptr(self.lut), n, h, w, _ptr(ws), _ptr(feat), _ptr(logits), _ptr(fmap),
+                                                _stream()), 'wsi_trunk_forward')
+        return feat, logits, fmap
+
+    def forward_f32(self, x, feat=False, logits=False, fmap=False, tap=None):
+        """x: (N,3,H,W) normalised fp32 on the GPU.  Returns (feat, logits, fmap) (None where not asked)."""
+        _require_gpu(x, 'input batch')
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected (N,3,H,W), got %s' % (tuple(x.shape),))
+        if logits and not self.head_k:
+            raise RuntimeError('no head set')
+        x = x.to(torch.float32).contiguous()
+        n, _, h, w = x.shape
+        if tap is not None:
+            return self._run(n, h, w, x, None, None, False, False, False, tap)
+        outs = [self._run(min(self.max_batch, n - i), h, w, x[i:i + self.max_batch], None, None, feat, logits, fmap)
+                for i in range(0, n, self.max_batch)]
+        return tuple(None if o[0] is None else (o[0] if len(o) == 1 else torch.cat(o)) for o in zip(*outs))
+
+    def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
+        """slide_u8: (SH,SW,3) uint8 GPU tensor (last two dims contiguous); tile_xy: (N,2) int32 GPU tensor of
+        top-left corners in slide pixels.  Tile read + transform are fused into the stem kernel."""
+        _require_gpu(slide_u8, 'slide')
+        _require_gpu(tile_xy, 'tile list')
+        if slide_u8.dtype != torch.uint8 or slide_u8.dim() != 3 or slide_u8.shape[2] != 3 or slide_u8.stride(2) != 1 \
+                or slide_u8.stride(1) != 3:
+            raise ValueError('slide must be (H,W,3) uint8 with packed RGB pixels')
+        if logits and not self.head_k:
+            raise RuntimeError('no head set')
+        tile_xy = tile_xy.to(torch.int32).contiguous()
+        n = tile_xy.shape[0]
+        if tap is not None:
+            return self._run(n, ph, pw, None, slide_u8, tile_xy, False, False, False, tap)
+        outs = [self._run(min(self.max_batch, n - i), ph, pw, None, slide_u8, tile_xy[i:i + self.max_batch], feat, logits,
+                          fmap) for i in range(0, n, self.max_batch)]
+        return tuple(None if o[0] is None else (o[0] if len(o) == 1 else torch.cat(o)) for o in zip(*outs))
+
+    # ------------------------------------------------------------------ small ops
+    def linear(self, x, weight, bias, relu=False):
+        _require_gpu(x, 'linear input')
+        x = x.to(torch.float32).contiguous()
+        weight = weight.detach().to(self.device, torch.float32).contiguous()
+        bias = bias.detach().to(self.device, torch.float32).contiguous() if bias is not None else None
+        y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=self.device)
+        native.check(self.lib.wsi_linear(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), x.shape[0], x.shape[1],
+                                         weight.shape[0], int(relu), _stream()), 'wsi_linear')
+        return y
+
+
+# ---------------------------------------------------------------------- standalone device ops
+def pf_pack(x, planes):
+    """f32 NCHW GPU tensor -> zero-initialised padded-flat buffer (uint8 tensor)."""
+    lib = native.load()
+    _require_gpu(x, 'pf_pack input')
+    x = x.to(torch.float32).contiguous()
+    n, c, h, w = x.shape
+    buf = torch.zeros(lib.wsi_pf_bytes(n, h, w, c, planes), dtype=torch.uint8, device=x.device)
+    native.check(lib.wsi_pf_pack(_ptr(x), _ptr(buf), n, c, h, w, planes, _stream()), 'wsi_pf_pack')
+    return buf
+
+
+def pf_unpack(buf, n, c, h, w, planes):
+    lib = native.load()
+    _require_gpu(buf, 'pf_unpack input')
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=buf.device)
+    native.check(lib.wsi_pf_unpack(_ptr(buf), _ptr(out), n, c, h, w, planes, _stream()), 'wsi_pf_unpack')
+    return out
+
+
+def pf_zeros(n, c, h, w, planes, device):
+    lib = native.load()
+    return torch.zeros(lib.wsi_pf_bytes(n, h, w, c, planes), dtype=torch.uint8, device=device)
+
+
+def prepack_conv(weight, bn, planes, device):
+    """weight (cout,cin,k,k) fp32; bn = (gamma, beta, mean, var) or None -> (wpk, bias) device tensors."""
+    lib = native.load()
+    w = np.ascontiguousarray(torch.as_tensor(weight).detach().cpu().to(torch.float32).numpy())
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    nbytes = lib.wsi_prepack_conv_bytes(cout, cin, k, planes)
+    if nbytes == 0:
+        raise ValueError('unsupported conv shape %s' % (w.shape,))
+    pk = np.empty(nbytes, np.uint8)
+    bias = np.empty(cout, np.float32)
+    if bn is None:
+        args = [None] * 4
+        keep = []
+    else:
+        keep = [np.ascontiguousarray(torch.as_tensor(t).detach().cpu().to(torch.float32).numpy()) for t in bn]
+        args = [_np_ptr(a) for a in keep]
+    native.check(lib.wsi_prepack_conv(_np_ptr(w), *args, BN_EPS, cout, cin, k, planes, _np_ptr(pk), _np_ptr(bias)),
+                 'wsi_prepack_conv')
+    return torch.from_numpy(pk).to(device), torch.from_numpy(bias).to(device)
+
+
+def conv_bn_act(x_pf, n, h, w, cin, cout, wpk, bias, stride=1, ksize=3, resid_pf=None, relu=True, planes=2):
+    lib = native.load()
+    out = pf_zeros(n, cout, h // stride, w // stride, planes, x_pf.device)
+    if ksize == 3:
+        rc = lib.wsi_conv3x3_bn_act(_ptr(x_pf), _ptr(out), _ptr(resid_pf), _ptr(wpk), _ptr(bias), n, h, w, cin, cout, stride,
+                                    int(relu), planes, _stream())
+    else:
+        rc = lib.wsi_conv1x1_bn(_ptr(x_pf), _ptr(out), _ptr(wpk), _ptr(bias), n, h, w, cin, cout, stride, planes, _stream())
+    native.check(rc, 'wsi_conv')
+    return out
+
+
+def tile_gather(slide_u8, tile_xy, ph, pw, lut):
+    """(SH,SW,3) u8 slide + (N,2) int32 corners -> normalised (N,3,ph,pw) fp32 (reference
+    utils/dataset.py:171-185 with the eval transform)."""
+    lib = native.load()
+    _require_gpu(slide_u8, 'slide')
+    tile_xy = tile_xy.to(slide_u8.device, torch.int32).contiguous()
+    n = tile_xy.shape[0]
+    out = torch.empty((n, 3, ph, pw), dtype=torch.float32, device=slide_u8.device)
+    native.check(lib.wsi_tile_gather(_ptr(slide_u8), slide_u8.stride(0), slide_u8.shape[0], slide_u8.shape[1],
+                                     _ptr(tile_xy), _ptr(lut), _ptr(out), n, ph, pw, _stream()), 'wsi_tile_gather')
+    return out
+
+
+def stitch_add(pred, tile_logits, map_xy, dy, dx):
+    """pred (C,MH,MW) float64 GPU += per-tile logits over dy x dx footprints at map_xy (T,2) int32."""
+    lib = native.load()
+    _require_gpu(pred, 'prediction map')
+    if pred.dtype != torch.float64 or not pred.is_contiguous():
+        raise ValueError('pred must be a contiguous float64 tensor')
+    tile_logits = tile_logits.to(torch.float32).contiguous()
+    map_xy = map_xy.to(pred.device, torch.int32).contiguous()
+    t, c = tile_logits.shape
+    native.check(lib.wsi_stitch_add(_ptr(tile_logits), _ptr(map_xy), t, c, dy, dx, _ptr(pred), pred.shape[1], pred.shape[2],
+                                    _stream()), 'wsi_stitch_add')
+    return pred
+
+
+def softmax_threshold_argmax(pred, class_probs, mask=None, heat_mode=None, want_probs=True):
+    """pred (C,H,W) float64 GPU -> (classes u8 (H,W), probs f64 (C,H,W) or None, heat u8 (H,W) or None)."""
+    lib = native.load()
+    _require_gpu(pred, 'prediction map')
+    pred = pred.contiguous()
+    c, h, w = pred.shape
+    th = torch.tensor([float(v) for v in class_probs][:c], dtype=torch.float64, device=pred.device)
+    probs = torch.empty_like(pred) if want_probs else None
+    classes = torch.empty((h, w), dtype=torch.uint8, device=pred.device)
+    heat = torch.empty((h, w), dtype=torch.uint8, device=pred.device) if heat_mode is not None else None
+    m = mask.to(pred.device, torch.uint8).contiguous() if mask is not None else None
+    native.check(lib.wsi_softmax_threshold_argmax(_ptr(pred), c, h * w, _ptr(th), _ptr(probs), _ptr(classes), _ptr(m),
+                                                  0 if heat_mode in (None, 'cls') else 1, _ptr(heat), _stream()),
+                 'wsi_softmax_threshold_argmax')
+    return classes, probs, heat

@@ -1,0 +1,94 @@
+"""ctypes binding of libwsi_hip.so (C ABI: include/wsi_hip.h).
+
+The product path has no CPU fallback: if the library is missing, ``load()`` raises and every caller
+fails loudly.  ``build()`` compiles the library in-tree with hipcc for gfx950 (works without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libwsi_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class WsiTrunkWeights(C.Structure):
+    _fields_ = [
+        ('stem_w', C.c_void_p), ('stem_b', C.c_void_p),
+        ('conv_w', C.c_void_p * 16), ('conv_b', C.c_void_p * 16),
+        ('down_w', C.c_void_p * 3), ('down_b', C.c_void_p * 3),
+        ('head_w', C.c_void_p), ('head_b', C.c_void_p), ('head_k', C.c_int),
+        ('planes', C.c_int),
+    ]
+
+
+_vp, _i, _ll, _sz, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_float
+# name -> (restype, argtypes); must list every symbol include/wsi_hip.h declares
+SIGNATURES = {
+    'wsi_hip_abi_version': (_i, []),
+    'wsi_pf_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'wsi_pf_pixel_index': (_ll, [_i, _i, _i, _i, _i]),
+    'wsi_prepack_conv_bytes': (_sz, [_i, _i, _i, _i]),
+    'wsi_prepack_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
+    'wsi_prepack_stem_bytes': (_sz, [_i]),
+    'wsi_prepack_stem': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
+    'wsi_normalize_u8_lut': (_i, [_vp, _vp, _vp]),
+    'wsi_stem_conv7x7_bn_relu_maxpool': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'wsi_conv3x3_bn_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wsi_conv1x1_bn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wsi_avgpool_fc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    'wsi_linear': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'wsi_pf_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'wsi_pf_unpack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'wsi_trunk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'wsi_trunk_workspace_init': (_i, [_vp, _i, _i, _i, _i, _vp]),
+    'wsi_trunk_forward': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'wsi_trunk_forward_tap': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'wsi_prof_begin': (_i, [_i]),
+    'wsi_prof_end': (_i, [_vp, _vp, _vp, _i]),
+    'wsi_tile_gather': (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'wsi_stitch_add': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    'wsi_softmax_threshold_argmax': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+}
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip into lib/libwsi_hip.so with hipcc --offload-arch=gfx950."""
+    res = subprocess.run(['make', '-C', CSRC, '-j8'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode:
+        print(res.stdout)
+    if res.returncode:
+        raise RuntimeError('hipcc build of libwsi_hip.so failed')
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            '%s not found: the WSI inference path has no CPU fallback - build it first '
+            '(python -c "import __graft_entry__ as g; g.build()" or make -C %s)' % (LIB_PATH, CSRC))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lost a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wsi_hip_abi_version() != 1:
+        raise RuntimeError('libwsi_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d (see include/wsi_hip.h error conventions)' % (what, rc))
