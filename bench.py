@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: patches/sec (256x256x3) whole-slide 'cls' inference on MI355X.
+
+Workload (BASELINE.json configs[1]): ResNet-18 trunk + Classifier on a synthetic, HBM-resident
+10 000-tile slide (tile 256, stride 256, reference grid utils/dataset.py:143-166), fused tile read
++ colour normalisation + conv stack on HIP kernels, per-tile logits stitched into the float64
+level-2 map and pushed through softmax/threshold/heat-map.  One "step" = one full pass over the
+slide.  With N ranks the slide grows to N x 10 000 tiles (weak scaling): the tile list is sharded
+contiguously, logits are exchanged with ONE RCCL all-gather, rank 0 stitches.
+
+Prints ONE JSON line (contract in the task brief) with `roofline` (3x3 stride-1 conv kernels, HIP
+events on the launch stream, live in the timed region) and `cpu_baseline` (the CPU oracle timed on
+this box's host cores over a bounded sample of the same tiles).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TILE = 256
+TILES_PER_GPU = 10000
+NX = 72                                   # (NX+1)*(NY+1) - 1 = 10 000 for NY = 136
+PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16, MI355X_MICROARCH.md chip table
+KIND_NAMES = {1: 'conv3x3_s1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool'}
+
+
+def slide_geometry(n_tiles):
+    ny = (n_tiles + 1 + NX) // (NX + 1) - 1
+    while (NX + 1) * (ny + 1) - 1 < n_tiles:
+        ny += 1
+    return 257 + NX * TILE, 257 + ny * TILE          # (iw, ih)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--mode', choices=('parity', 'speed'), default='parity',
+                    help='parity: bf16x2 split, 3 MFMA passes (meets 1e-3); speed: single-pass bf16')
+    ap.add_argument('--batch', type=int, default=250)
+    ap.add_argument('--tiles', type=int, default=TILES_PER_GPU, help='tiles per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='disable per-launch HIP events (roofline leg)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the inference path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from wsi_segmentation_pipeline_amd import native, slide as S
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine, PARITY, SPEED
+    from wsi_segmentation_pipeline_amd import synthetic as W   # seeded checkpoint (no trained one exists offline)
+
+    planes = PARITY if args.mode == 'parity' else SPEED
+    lib = native.load()
+    sd = W.make_resnet18_state_dict(11, with_fc=False)
+    cls = W.make_head_state_dict(22, 'classifier')
+    eng = TrunkEngine(sd, dev, planes=planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch)
+
+    total_tiles = args.tiles * world
+    iw, ih = slide_geometry(total_tiles)
+    g = torch.Generator(device=dev).manual_seed(3)
+    level0 = torch.randint(0, 256, (ih, iw, 3), dtype=torch.uint8, device=dev, generator=g)   # same on every rank
+    tiles = S.tile_grid(iw, ih, TILE, TILE, TILE, TILE)[:total_tiles]
+    assert len(tiles) == total_tiles, (len(tiles), total_tiles)
+    m = 1.0 / 16.0                                       # downsample[0] / downsample[2]
+    map_hw = (ih // 16, iw // 16)
+    mask = torch.ones(map_hw, dtype=torch.uint8, device=dev)
+    class_probs = (0., 0., 0., 0.)
+
+    def step():
+        return S.infer_slide_cls(eng, level0, tiles, TILE, TILE, m, map_hw, 4, class_probs, mask, rank, world,
+                                 want_probs=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof_on = not args.no_prof
+    launches_per_step = 21 * ((args.tiles + args.batch - 1) // args.batch)
+    if prof_on and launches_per_step * args.steps <= 16384:
+        native.check(lib.wsi_prof_begin(launches_per_step * args.steps), 'wsi_prof_begin')
+    else:
+        prof_on = False
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    roofline = None
+    per_kind = {}
+    if prof_on:
+        cap = launches_per_step * args.steps
+        ms = np.zeros(cap, np.float32)
+        kind = np.zeros(cap, np.int32)
+        fl = np.zeros(cap, np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        nrec = lib.wsi_prof_end(p(ms), p(kind), p(fl), cap)
+        assert nrec >= 0
+        for k, name in KIND_NAMES.items():
+            sel = kind[:nrec] == k
+            if sel.any():
+                tms, tfl = float(ms[:nrec][sel].sum()), float(fl[:nrec][sel].sum())
+                per_kind[name] = {'launches': int(sel.sum()), 'avg_ms': tms / int(sel.sum()),
+                                  'tflops': tfl / (tms * 1e-3) / 1e12, 'share_of_step': tms * 1e-3 / dt}
+        if 'conv3x3_s1' in per_kind:
+            ach = per_kind['conv3x3_s1']['tflops']
+            roofline = {'kernel': 'conv3x3s1_slab_kernel (12 launches per batch: layer1-4 stride-1 3x3 convs)',
+                        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                        'avg_launch_ms': round(per_kind['conv3x3_s1']['avg_ms'], 4),
+                        'mfma_passes': 3 if planes == 2 else 1}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = total_tiles * args.steps / dt
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import resnet_oracle as R
+        nsample = 32
+        xy = tiles[:nsample]
+        u8 = torch.stack([level0[y:y + TILE, x:x + TILE] for x, y in xy]).permute(0, 3, 1, 2).contiguous().cpu().numpy()
+        cores = torch.get_num_threads()
+        with torch.no_grad():
+            ref = R.tile_logits(sd, cls, u8)                                 # warm-up (also a sanity check)
+            ts = []
+            for _ in range(3):
+                c0 = time.perf_counter()
+                R.tile_logits(sd, cls, u8)
+                ts.append(time.perf_counter() - c0)
+        got = out['logits'][:nsample].cpu()
+        cpu_baseline = {'value': round(nsample / float(np.median(ts)), 2), 'unit': 'patches/s', 'cores': cores,
+                        'kind': 'port', 'sample': 'first %d tiles of the same slide, fp32 torch CPU oracle, median of 3' % nsample,
+                        'max_abs_logit_diff_vs_gpu': float((got - ref).abs().max())}
+
+    if rank == 0:
+        line = {
+            'metric': 'patches/sec (256x256x3) whole-slide inference', 'value': round(value, 1), 'unit': 'patches/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16x2-split (3 MFMA passes, fp32 accumulate)' if planes == 2 else 'bf16 (fp32 accumulate)',
+            'data': 'synthetic (seeded u8 slide resident in HBM, seeded random ResNet-18 weights)',
+            'config': {'workload': 'cfg2: ResNet-18 trunk + Classifier, %d-tile slide per GPU, tile 256 stride 256, '
+                                   'fused read+normalise+conv HIP path, float64 stitch + softmax' % args.tiles,
+                       'tiles_total': total_tiles, 'batch': args.batch, 'mode': args.mode,
+                       'parallelism': 'tile-shard x%d + 1 all-gather' % world},
+            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'kernels': per_kind,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -227,7 +227,7 @@ int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const 
 // ------------------------------------------------------------------------------------ profiler
 // Optional HIP-event timing of every conv launch made by wsi_trunk_forward, on the stream the
 // kernels run on (bench.py's roofline leg).  Off by default; never active inside graph capture.
-#define WSI_PROF_MAX 4096
+#define WSI_PROF_MAX 16384
 static struct {
     int enabled, count, cap;
     hipEvent_t ev[2 * WSI_PROF_MAX];
