@@ -1,0 +1,149 @@
+"""Drop-in for the reference's ``resnets_shift`` module: the bag-of-patches ResNet-18.
+
+Same public names, constructor arguments, 130 state-dict keys and output convention as
+/root/reference/resnets_shift.py (ResNet :111-217, resnet18 :219-242), so existing checkpoints
+load and ``train_hr.py`` / ``scannet.py`` / ``slic.py``-style callers import it unchanged.
+In eval mode ``forward`` runs entirely on the gfx950 HIP kernels (libwsi_hip.so) and refuses CPU
+tensors - there is no CPU fallback.  In training mode (autograd needed, out of the inference hot
+path) the same parameters are evaluated with torch ops so the training scripts keep working.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ['ResNet', 'BasicBlock', 'resnet18', 'conv3x3', 'conv1x1']
+
+HR_NUM_CNT_SAMPLES = 8       # reference utils/dataset_hr.py:14-15 (kept here to avoid a circular import)
+HR_NUM_PERIM_SAMPLES = 8
+
+model_urls = {'resnet18': 'https://download.pytorch.org/models/resnet18-5c106cde.pth'}
+
+
+def conv3x3(in_planes, out_planes, stride=1, groups=1):
+    return nn.Conv2d(in_planes, out_planes, 3, stride, 1, groups=groups, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, 1, stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """Parameter container for one residual block (keys conv1/bn1/conv2/bn2/downsample.{0,1})."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, norm_layer=None):
+        super().__init__()
+        if groups != 1 or base_width != 64:
+            raise ValueError('BasicBlock only supports groups=1 and base_width=64')
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1, self.bn1 = conv3x3(inplanes, planes, stride), norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2, self.bn2 = conv3x3(planes, planes), norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):          # torch-op path: training / autograd only
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNet(nn.Module):
+    """forward(xs: (B,P,3,H,W)) -> (per-patch logits (P*B,4) patch-major, ensemble logits (B,4))."""
+
+    def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
+                 norm_layer=None, precision='parity'):
+        super().__init__()
+        if block is not BasicBlock or list(layers) != [2, 2, 2, 2]:
+            raise NotImplementedError('the HIP path implements the ResNet-18 configuration used by resnet18()')
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.inplanes, self.groups, self.base_width = 64, groups, width_per_group
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        for i, (planes, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), start=1):
+            setattr(self, 'layer%d' % i, self._make_layer(block, planes, layers[i - 1], stride, norm_layer))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        bag = HR_NUM_CNT_SAMPLES + HR_NUM_PERIM_SAMPLES
+        width = 512 * block.expansion
+        self.fc = nn.Sequential(nn.Linear(width * bag, width * bag // 2), nn.ReLU(True), nn.Linear(width * bag // 2, 4))
+        self.fc0 = nn.Linear(width, 4)
+        self.fc1 = nn.Sequential(nn.Linear(width, 16), nn.ReLU(True))        # unused by forward (as in the reference)
+        self.fc2 = nn.Sequential(nn.Linear(16 * bag, 4))
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(mod, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.ones_(mod.weight)
+                nn.init.zeros_(mod.bias)
+        if zero_init_residual:
+            for mod in self.modules():
+                if isinstance(mod, BasicBlock):
+                    nn.init.zeros_(mod.bn2.weight)
+        self.precision = precision           # 'parity' (bf16x2 split, <=1e-3 logits) or 'speed' (single bf16)
+        self._engine = None
+        self._engine_sig = None
+
+    def _make_layer(self, block, planes, blocks, stride, norm_layer):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride), norm_layer(planes * block.expansion))
+        seq = [block(self.inplanes, planes, stride, down, self.groups, self.base_width, norm_layer)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes, groups=self.groups, base_width=self.base_width, norm_layer=norm_layer)
+                for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    # ------------------------------------------------------------------ HIP engine plumbing
+    def hip_engine(self, device=None):
+        """TrunkEngine over the current parameters (rebuilt when they change or move)."""
+        from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+        device = torch.device(device) if device is not None else self.conv1.weight.device
+        sig = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters()) \
+            + tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if self._engine is None or sig != self._engine_sig:
+            self._engine = TrunkEngine(self.state_dict(), device, planes=2 if self.precision == 'parity' else 1,
+                                       head=(self.fc0.weight, self.fc0.bias))
+            self._engine_sig = sig
+        return self._engine
+
+    def features(self, x):
+        """(N,3,H,W) normalised fp32 on the GPU -> (N,512,H/32,W/32) via the HIP trunk."""
+        return self.hip_engine(x.device).forward_f32(x, fmap=True)[2]
+
+    def _forward_autograd(self, xs):
+        B, P = xs.shape[:2]
+        feats, singles = [], []
+        for x in xs.transpose(0, 1):
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            x = torch.flatten(self.avgpool(self.layer4(self.layer3(self.layer2(self.layer1(x))))), 1)
+            singles.append(self.fc0(x))
+            feats.append(x)
+        return torch.cat(singles, 0), self.fc(torch.cat(feats, 1).view(B, -1))
+
+    def forward(self, xs):
+        if xs.dim() != 5:
+            raise ValueError('expected a bag tensor (B,P,3,H,W)')
+        if self.training:
+            return self._forward_autograd(xs)
+        if not xs.is_cuda:
+            raise RuntimeError('resnets_shift.ResNet eval forward runs on HIP kernels only: move the model and the '
+                               'input to the GPU (no CPU fallback)')
+        B, P = xs.shape[:2]
+        eng = self.hip_engine(xs.device)
+        feat, logits, _ = eng.forward_f32(xs.reshape(B * P, *xs.shape[2:]), feat=True, logits=True)
+        singles = logits.view(B, P, -1).transpose(0, 1).reshape(P * B, -1)            # row = p*B + b
+        hidden = eng.linear(feat.view(B, P * feat.shape[1]), self.fc[0].weight, self.fc[0].bias, relu=True)
+        return singles, eng.linear(hidden, self.fc[2].weight, self.fc[2].bias)
+
+
+def resnet18(pretrained=False, **kwargs):
+    """ResNet-18 bag model; ``pretrained`` overlays the ImageNet trunk weights (needs network access)."""
+    model = ResNet(BasicBlock, [2, 2, 2, 2], **kwargs)
+    if pretrained:
+        import torch.utils.model_zoo as model_zoo
+        own = model.state_dict()
+        own.update({k: v for k, v in model_zoo.load_url(model_urls['resnet18']).items() if k in own})
+        model.load_state_dict(own)
+    return model

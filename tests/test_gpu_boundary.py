@@ -1,0 +1,174 @@
+"""GPU parity of the reference-named drop-in modules (resnets_shift, models.models, utils.eval,
+utils.dataset, utils.dataset_hr) - written the way a reference-side caller uses them - against the
+golden vectors and the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.argv = sys.argv[:1]
+from oracle import resnet_oracle as R          # noqa: E402
+from oracle import weights as W                # noqa: E402
+from oracle import wsi_oracle as WO            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def sd_full():
+    return W.make_resnet18_state_dict(11)
+
+
+def test_resnets_shift_bag_forward_matches_golden(dev, sd_full, golden_dir):
+    import resnets_shift
+    g = np.load(os.path.join(golden_dir, 'resnet18_bag64.npz'))
+    model = resnets_shift.resnet18(False)
+    model.load_state_dict(sd_full)
+    model = model.cuda().eval()
+    shape = tuple(int(v) for v in g['input_shape'])
+    u8 = W.make_u8_patches(int(g['input_seed']), shape)
+    xs = R.normalize_u8(u8.reshape(-1, *shape[2:])).view(*shape)
+    with torch.no_grad():
+        singles, ens = model(xs.cuda())
+    assert singles.shape == (32, 4) and ens.shape == (2, 4)
+    assert np.abs(singles.cpu().numpy() - g['singles']).max() <= LOGIT_TOL
+    assert np.abs(ens.cpu().numpy() - g['ensemble']).max() <= LOGIT_TOL
+    with pytest.raises(RuntimeError):
+        model(xs)                                     # CPU tensor: loud failure, no fallback
+    # reloading weights invalidates the prepacked engine
+    sd2 = W.make_resnet18_state_dict(12)
+    model.load_state_dict(sd2)
+    with torch.no_grad():
+        s2, _ = model(xs.cuda())
+        ref2, _ = R.resnet_forward(sd2, xs)
+    assert np.abs(s2.cpu().numpy() - ref2.numpy()).max() <= LOGIT_TOL
+
+
+def test_heads_match_golden(dev, golden_dir):
+    from models.models import Classifier, Regressor
+    g = np.load(os.path.join(golden_dir, 'heads.npz'))
+    rng = np.random.Generator(np.random.PCG64(int(g['fmap_seed'])))
+    fmap = torch.from_numpy(rng.standard_normal((5, 512, 8, 8), dtype=np.float32)).abs_()
+    cls = Classifier(512, 4)
+    cls.load_state_dict(W.make_head_state_dict(int(g['cls_seed']), 'classifier'))
+    reg = Regressor(512, 1)
+    reg.load_state_dict(W.make_head_state_dict(int(g['reg_seed']), 'regressor', num_classes=1))
+    cls, reg = cls.cuda().eval(), reg.cuda().eval()
+    with torch.no_grad():
+        assert np.abs(cls(fmap.cuda()).cpu().numpy() - g['classifier']).max() <= 1e-4
+        assert np.abs(reg(fmap.cuda()).cpu().numpy() - g['regressor']).max() <= 1e-4
+
+
+def _he_slide(seed, h, w):
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w, 3), 255, np.uint8)
+    for _ in range(40):
+        y, x = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 40))
+        hh, ww = int(rng.integers(30, 200)), int(rng.integers(30, 200))
+        col = np.array([rng.integers(90, 200), rng.integers(20, 120), rng.integers(120, 220)])
+        blob = np.clip(col + rng.integers(-25, 25, (min(hh, h - y), min(ww, w - x), 3)), 0, 255)
+        img[y:y + hh, x:x + ww] = blob.astype(np.uint8)
+    return img
+
+
+@pytest.mark.parametrize('stride', [64, 32])
+def test_predict_tumorbed_cls_matches_oracle(dev, sd_full, tmp_path, stride):
+    import myargs
+    import resnets_shift
+    import utils.dataset as ds
+    import utils.eval as val
+    from models.models import Classifier
+    from wsi_segmentation_pipeline_amd.slide import ArraySlide
+    a = myargs.args
+    a.scan_level, a.scan_resize, a.num_classes, a.class_probs = 0, 1, 4, [0., 0., 0., 0.]
+    a.tile_w = a.tile_h = 64
+    a.tile_stride_w = a.tile_stride_h = stride
+    a.val_save_pth, a.wsi_mask_pth = str(tmp_path / 'out'), str(tmp_path / 'nomask')
+    l0 = _he_slide(3, 904, 1112)
+    slide = ArraySlide([l0, l0[::4, ::4], l0[::16, ::16]], [1.0, 4.0, 16.0])
+    slide.name = 'synthetic.svs'
+    cls_sd = W.make_head_state_dict(22, 'classifier')
+    params = {'ph': 64, 'pw': 64, 'sh': stride, 'sw': stride}
+
+    # ---- oracle: reference algorithm restated on the CPU
+    mask = WO.find_nuclei_hsv(slide.level_array(2))
+    m = 1.0 / 16.0
+    tiles = WO.tile_grid(l0.shape[1], l0.shape[0], 64, 64, stride, stride, mask, m)
+    assert 20 < len(tiles) < 1000
+    u8 = np.stack([WO.read_tile(l0, x, y, 64, 64) for x, y in tiles]).transpose(0, 3, 1, 2)
+    with torch.no_grad():
+        ref_logits = R.tile_logits(sd_full, cls_sd, u8).numpy()
+    pred = WO.stitch_tumorbed(tiles, ref_logits, 4, mask.shape, m, 64, 64)
+    ref_cls, ref_probs = WO.threshold_probs(pred)
+    ref_heat = WO.tumorbed_heatmap(ref_probs, mask, 'cls')
+
+    # ---- product, driven like eval_tumorbed.py drives the reference
+    net = resnets_shift.resnet18(False)
+    net.load_state_dict(sd_full)
+    head = Classifier(512, 4)
+    head.load_state_dict(cls_sd)
+    for fused in (True, False):
+        dataset = ds.Dataset_wsis({'synthetic.svs': slide}, params, bs=16)
+        assert dataset.wsis['synthetic.svs']['iterator'].dataset.datalist == [tuple(t) for t in tiles]
+        model = val.SlideClassifierModel(net, head).cuda()
+        if not fused:                         # plain nn.Module with .encoder/.classifier: generic iterator loop
+            plain = torch.nn.Module()
+            plain.encoder, plain.classifier = model.encoder, model.classifier
+            model = plain.cuda()
+        res = val.predict_tumorbed(model, dataset, 7, mode='cls')['synthetic.svs']
+        assert np.abs(res['logits'].cpu().numpy() - ref_logits).max() <= LOGIT_TOL
+        diff = np.abs(res['heatmap'].astype(int) - ref_heat.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
+        assert (res['classes'] != ref_cls).mean() < 0.01
+        assert os.path.exists('%s/7/synthetic.svs_%d_heatmap.png' % (a.val_save_pth, stride))
+        assert os.path.exists('%s/7/synthetic.svs_%d_overlay.png' % (a.val_save_pth, stride))
+        assert dataset.wsis['synthetic.svs'] is None
+
+
+def test_region_bags_and_paint_match_oracle(dev, sd_full):
+    import myargs
+    import resnets_shift
+    import utils.eval as val
+    from utils.dataset_hr import GenerateIterator_eval
+    from wsi_segmentation_pipeline_amd.slide import ArraySlide
+    myargs.args.batch_size = 3
+    myargs.args.class_probs = [0., 0., 0., 0.]
+    rng = np.random.default_rng(4)
+    l0 = rng.integers(0, 256, (1024, 1536, 3), dtype=np.uint8)
+    slide = ArraySlide([l0, l0[::4, ::4], l0[::16, ::16]], [1.0, 4.0, 16.0])
+    label_shape = (64, 96)                                     # thumbnail at scan_level 2 (x16)
+    metadata = {}
+    for rid in range(7):
+        npts = int(rng.integers(6, 14))
+        ys, xs = np.nonzero(rng.random(label_shape) < 0.02 * (rid + 1))
+        metadata[rid] = {'cnt_xy': rng.integers(0, [96, 64], (npts, 2)), 'perim_xy': rng.integers(0, [96, 64], (npts + 2, 2)),
+                         'wsipath': 'unused', 'scan_level': 2, 'foreground_indices': (ys, xs), 'tile_id': rid}
+    bags = WO.build_bags(metadata, 1536, 1024)
+    assert 2 <= len(bags) <= 7
+    crops = np.stack([WO.read_bag(slide.level_array(1), c, 4.0) for _, c in bags])          # (R,16,64,64,3)
+    xs_ref = R.normalize_u8(crops.reshape(-1, 64, 64, 3).transpose(0, 3, 1, 2)).view(len(bags), 16, 3, 64, 64)
+    with torch.no_grad():
+        _, ens_ref = R.resnet_forward(sd_full, xs_ref)
+    ref_mask = WO.paint_regions(label_shape, metadata, [t for t, _ in bags], ens_ref.numpy())
+
+    model = resnets_shift.resnet18(False)
+    model.load_state_dict(sd_full)
+    model = model.cuda().eval()
+    it = GenerateIterator_eval(metadata, scan=slide)
+    assert [r['tile_id'] for r in it.dataset.datalist] == [t for t, _ in bags]
+    got_bags = torch.cat([b for b, _ in it]).cpu()
+    assert torch.equal(got_bags, xs_ref)
+    with torch.no_grad():
+        _, ens = model(got_bags.cuda())
+    assert np.abs(ens.cpu().numpy() - ens_ref.numpy()).max() <= LOGIT_TOL
+    got_mask = val.predict_regions(model, it, metadata, label_shape)
+    assert np.array_equal(got_mask, ref_mask)
