@@ -67,6 +67,11 @@ int wsi_conv3x3_bn_act(const void* in_pf, void* out_pf, const void* resid_pf, co
                        void* stream);
 int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,
                    int cin, int cout, int stride, int planes, void* stream);
+/* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
+ * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */
+int wsi_conv3x3_bn_act_cfg(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,
+                           int n, int h_in, int w_in, int cin, int cout, int stride, int relu, int planes, int cfg,
+                           void* stream);
 
 /* ---- heads -----------------------------------------------------------------------------------
  * avgpool_fc: AdaptiveAvgPool2d(1) + flatten (+ Linear(c -> k)) (resnets_shift.py:206-208,

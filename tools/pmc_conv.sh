@@ -1,0 +1,8 @@
+#!/bin/bash
+# PMC counters for the conv tuning harness (counters in their own passes, no trace domains).
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/pmc_$1; shift
+mkdir -p $OUT
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/a -- python3 tools/tune_conv.py --rounds 1 --iters 2 "$@" > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- python3 tools/tune_conv.py --rounds 1 --iters 2 "$@" > $OUT/b.log 2>&1
+echo done

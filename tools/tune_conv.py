@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""On-GPU tuning of the stride-1 3x3 slab kernel: times every tile configuration on the four
+ResNet-18 layer shapes (interleaved rounds in one process) and checks all configurations give
+bit-identical outputs.  Usage: python tools/tune_conv.py [--n 250] [--planes 2] [--rounds 5]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wsi_segmentation_pipeline_amd import engine as E, native  # noqa: E402
+
+SHAPES = [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]      # (C, H, W) for 256x256 patches
+NCFG = 10
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--n', type=int, default=250)
+    ap.add_argument('--planes', type=int, default=2)
+    ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
+    args = ap.parse_args()
+    lib = native.load()
+    dev = torch.device('cuda:0')
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(0)
+    for (c, h, w) in SHAPES:
+        h, w = h // args.scale, w // args.scale
+        n = args.n
+        x = torch.randn(n, c, h, w, generator=g).abs_()
+        wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+        wpk, bias = E.prepack_conv(wt, None, args.planes, dev)
+        xpf = E.pf_pack(x.to(dev), args.planes)
+        rpf = E.pf_pack(torch.randn(n, c, h, w, generator=g).to(dev), args.planes)
+        outs = {cfg: E.pf_zeros(n, c, h, w, args.planes, dev) for cfg in range(NCFG)}
+        flops = 2.0 * n * h * w * c * c * 9
+
+        def run(cfg):
+            return lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), outs[cfg].data_ptr(), rpf.data_ptr(), wpk.data_ptr(), bias.data_ptr(),
+                                              n, h, w, c, c, 1, 1, args.planes, cfg, st())
+        valid = [cfg for cfg in range(NCFG) if run(cfg) == 0]
+        torch.cuda.synchronize()
+        ref = outs[valid[0]]
+        same = {cfg: bool(torch.equal(outs[cfg], ref)) for cfg in valid}
+        times = {cfg: [] for cfg in valid}
+        for _ in range(args.rounds):
+            for cfg in valid:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    run(cfg)
+                e1.record()
+                torch.cuda.synchronize()
+                times[cfg].append(e0.elapsed_time(e1) / args.iters)
+        print('shape C=%d %dx%d n=%d planes=%d  (%.1f GFLOP)' % (c, h, w, n, args.planes, flops / 1e9))
+        for cfg in valid:
+            med, mn = float(np.median(times[cfg])), float(np.min(times[cfg]))
+            print('  cfg %d: median %.3f ms  min %.3f ms  -> %.1f TFLOP/s algorithmic  identical=%s' %
+                  (cfg, med, mn, flops / med / 1e9, same[cfg]))
+
+
+if __name__ == '__main__':
+    main()

@@ -5,7 +5,7 @@
 #include <math.h>
 #include <string.h>
 
-int wsi_conv_dispatch(const ConvArgs& a, int planes, hipStream_t st);
+int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
 int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
@@ -160,7 +160,8 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
 }
 
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
-                       int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream) {
+                       int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
+                       int cfg = -1) {
     if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
     if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
     ConvArgs a;
@@ -168,13 +169,19 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.gi = pf_geom(n, h_in, w_in, cin);
     a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
     a.stride = stride; a.ksize = ksize; a.relu = relu;
-    return wsi_conv_dispatch(a, planes, (hipStream_t)stream);
+    return wsi_conv_dispatch(a, planes, cfg, (hipStream_t)stream);
 }
 
 int wsi_conv3x3_bn_act(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,
                        int n, int h_in, int w_in, int cin, int cout, int stride, int relu, int planes,
                        void* stream) {
     return conv_common(in_pf, out_pf, resid_pf, wpk, bias, n, h_in, w_in, cin, cout, stride, 3, relu, planes, stream);
+}
+
+int wsi_conv3x3_bn_act_cfg(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,
+                           int n, int h_in, int w_in, int cin, int cout, int stride, int relu, int planes, int cfg,
+                           void* stream) {
+    return conv_common(in_pf, out_pf, resid_pf, wpk, bias, n, h_in, w_in, cin, cout, stride, 3, relu, planes, stream, cfg);
 }
 
 int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,

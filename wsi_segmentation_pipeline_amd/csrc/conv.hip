@@ -93,11 +93,19 @@ static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8
 static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128 + ((h ^ ((Pl >> 1) & 7)) << 4); }
 
 // --------------------------------------------------------------------------------------------
+// 16-byte LDS-DMA: lane i writes LDS [lds_wave_base + 16*i] from its own global address.
+static __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // Stride-1 3x3: the input pixels a tile of BM consecutive PF positions needs form ONE contiguous
-// range [q0-P-1, q0+BM+P+1): stage that slab once per 128-byte line, then all nine taps are LDS
-// address shifts.  Wave (wm, wn) computes pixels [wm*MT*32, +MT*32) x couts [32*(nb*WN+wn), +32).
-template <int MT, int WM, int WN, int PLANES>
-__global__ __launch_bounds__(WM* WN * 64) void conv3x3s1_slab_kernel(ConvArgs a) {
+// range [q0-P-1, q0+BM+P+1): stage that slab once per 128-byte line by LDS-DMA (all pieces in
+// flight at once, swizzle applied on the source address), then all nine taps are LDS address
+// shifts.  Wave (wm, wn) computes pixels [wm*MT*32, +MT*32) x couts [32*(nb*WN+wn), +32); its
+// weight fragments are prefetched one tap ahead straight into registers.
+template <int MT, int WM, int WN, int PLANES, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
     constexpr int NTHREADS = WM * WN * 64;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3s1_slab_kernel(ConvArgs a)
     const int mtile = blockIdx.x / nblocks;
     const int P = a.gi.P;
     const int q0 = a.gi.G + mtile * BM;
-    const int slab_px = BM + 2 * P + 2;
+    const int npieces = (BM + 2 * P + 2) * 8;                 // 16-byte pieces in the slab
     const int ntile = nb * WN + wn;
     const int NC = a.gi.C * PLANES / 64;
     const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
@@ -122,25 +130,37 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3s1_slab_kernel(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
+    int xoff[MT];                                             // slab-local pixel of each tile row (tap 0,0 adds toff)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
+
     for (int c = 0; c < NC; ++c) {
-        if (c) __syncthreads();
-        for (int i = tid; i < slab_px * 8; i += NTHREADS) {
+        const bf16x8* wp = wbase + (size_t)c * 9 * 4 * 64;
+        bf16x8 wcur[4], wnxt[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wcur[f] = wp[f * 64];     // tap 0 weights fly during the slab DMA
+        if (c) __syncthreads();                               // every wave is done reading the previous line
+        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
+            const int i = i0 + lane;
             const int Pl = i >> 3, sp = i & 7;
             const int s = sp ^ ((Pl >> 1) & 7);
-            *(uint4*)(smem + (size_t)i * 16) = *(const uint4*)(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16);
+            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16, smem + (size_t)i0 * 16);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const bf16x8* wp = wbase + (size_t)c * 9 * 4 * 64;
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
-            bf16x8 wf[4];
+            if (t < 8) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) wf[f] = wp[(t * 4 + f) * 64];
+                for (int f = 0; f < 4; ++f) wnxt[f] = wp[((t + 1) * 4 + f) * 64];
+            }
             const int toff = (t / 3 - 1) * P + (t % 3 - 1) + P + 1;
             int xbase[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(wm * MT * 32 + mt * 32 + l31 + toff, h);
-            mfma_line<MT, PLANES>(acc, wf, smem, xbase);
+            for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(xoff[mt] + toff, h);
+            mfma_line<MT, PLANES>(acc, wcur, smem, xbase);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wcur[f] = wnxt[f];
         }
     }
     conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
@@ -221,25 +241,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-template <int MT, int WM, int WN, int PLANES>
+template <int MT, int WM, int WN, int PLANES, int MINW>
 static int launch_slab(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = WM * MT * 32;
+    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
+    if (a.go.C % (WN * 32)) return WSI_EINVAL;
     const int mtiles = (a.gi.NS + BM - 1) / BM;
     const int nblocks = a.go.C / (WN * 32);
-    const size_t lds = (size_t)(BM + 2 * a.gi.P + 2) * 128;
+    const int npieces = (BM + 2 * a.gi.P + 2) * 8;
+    const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;   // whole DMA rounds
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_slab_kernel<MT, WM, WN, PLANES>;
+    auto k = conv3x3s1_slab_kernel<MT, WM, WN, PLANES, MINW>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
 template <int MT, int WM, int WN, int PLANES>
 static int launch_gather(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32;
+    if (a.go.C % (WN * 32)) return WSI_EINVAL;
     const int mtiles = (a.go.NS + BM - 1) / BM;
     const int nblocks = a.go.C / (WN * 32);
     const size_t lds = (size_t)BM * 128;
@@ -247,15 +270,40 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-// Host dispatch.  Tile shapes: every wave owns 32 output channels (weights stay in its
-// registers for a whole tap) and MT*32 pixels; WN waves share one pixel slab.
-int wsi_conv_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
+// Slab tile configurations (cfg index -> MT, WM, WN, min waves/SIMD).  Every wave owns 32 output
+// channels and MT*32 pixels; WN waves share one pixel slab; BM = WM*MT*32, BN = WN*32.
+#define SLAB_CFGS(X)  \
+    X(0, 8, 1, 4, 1)  \
+    X(1, 8, 1, 4, 2)  \
+    X(2, 4, 1, 4, 2)  \
+    X(3, 4, 2, 2, 2)  \
+    X(4, 4, 2, 4, 2)  \
+    X(5, 8, 1, 2, 2)  \
+    X(6, 8, 2, 2, 2)  \
+    X(7, 2, 2, 4, 2)  \
+    X(8, 4, 4, 2, 2)  \
+    X(9, 4, 1, 2, 2)
+
+int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
+    switch (cfg) {
+#define X(id, MT, WM, WN, MINW) \
+    case id: return planes == 2 ? launch_slab<MT, WM, WN, 2, MINW>(a, st) : launch_slab<MT, WM, WN, 1, MINW>(a, st);
+        SLAB_CFGS(X)
+#undef X
+    }
+    return WSI_EINVAL;
+}
+
+// default config per layer shape (tuned on MI355X, tools/tune_conv.py)
+static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 2 : 3; }   // r01 tune: profiles/r01_tune_conv.log
+
+// Host dispatch.  cfg < 0 selects the tuned default.
+int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     const int cout = a.go.C;
     if (a.gi.C % 64 || cout % 64 || (planes != 1 && planes != 2)) return WSI_EINVAL;
     if (a.ksize == 3 && a.stride == 1) {
         if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;
-        if (cout % 128 == 0) return planes == 2 ? launch_slab<8, 1, 4, 2>(a, st) : launch_slab<8, 1, 4, 1>(a, st);
-        return planes == 2 ? launch_slab<4, 2, 2, 2>(a, st) : launch_slab<4, 2, 2, 1>(a, st);
+        return wsi_slab_dispatch_cfg(a, planes, cfg < 0 ? slab_default_cfg(a) : cfg, st);
     }
     if ((a.ksize == 3 || a.ksize == 1) && (a.stride == 1 || a.stride == 2)) {
         if (a.go.H * a.stride != a.gi.H || a.go.W * a.stride != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;

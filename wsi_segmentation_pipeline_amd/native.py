@@ -41,6 +41,7 @@ SIGNATURES = {
     'wsi_normalize_u8_lut': (_i, [_vp, _vp, _vp]),
     'wsi_stem_conv7x7_bn_relu_maxpool': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'wsi_conv3x3_bn_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wsi_conv3x3_bn_act_cfg': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_conv1x1_bn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_avgpool_fc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     'wsi_linear': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
