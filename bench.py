@@ -46,8 +46,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--mode', choices=('parity', 'speed'), default='parity',
                     help='parity: bf16x2 split, 3 MFMA passes (meets 1e-3); speed: single-pass bf16')
-    ap.add_argument('--batch', type=int, default=250)
+    ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--tiles', type=int, default=TILES_PER_GPU, help='tiles per GPU per step')
+    ap.add_argument('--chunks', type=str, default='', help='stem_chunk,layer1_chunk sub-batch sizes (default: library default)')
+    ap.add_argument('--streams', type=int, default=1, help='batches in flight (HIP streams); >1 distorts per-kernel timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='disable per-launch HIP events (roofline leg)')
     args = ap.parse_args()
@@ -73,9 +75,13 @@ def main():
 
     planes = PARITY if args.mode == 'parity' else SPEED
     lib = native.load()
+    if args.chunks:
+        cs, c1 = (int(v) for v in args.chunks.split(','))
+        native.check(lib.wsi_trunk_set_chunks(cs, c1), 'wsi_trunk_set_chunks')
     sd = W.make_resnet18_state_dict(11, with_fc=False)
     cls = W.make_head_state_dict(22, 'classifier')
-    eng = TrunkEngine(sd, dev, planes=planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch)
+    eng = TrunkEngine(sd, dev, planes=planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch,
+                      streams=args.streams)
 
     total_tiles = args.tiles * world
     iw, ih = slide_geometry(total_tiles)
@@ -102,7 +108,7 @@ def main():
         step()
     fence()
     prof_on = not args.no_prof
-    launches_per_step = 21 * ((args.tiles + args.batch - 1) // args.batch)
+    launches_per_step = (21 if not args.chunks else 200) * ((args.tiles + args.batch - 1) // args.batch)
     if prof_on and launches_per_step * args.steps <= 16384:
         native.check(lib.wsi_prof_begin(launches_per_step * args.steps), 'wsi_prof_begin')
     else:

@@ -59,6 +59,11 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
                                      const void* stem_wpk, const float* stem_bias, int n, int h, int w,
                                      float* scratch, void* out_pf, int planes, void* stream);
 
+/* tuning / A-B hook: fused = 1 (default) runs the single fused stem+maxpool kernel (no fp32
+ * intermediate; scratch unused), fused = 0 the two-kernel form; rows_per_seg = pooled rows per
+ * workgroup of the fused kernel (default 16).  Process-wide. */
+int wsi_stem_set_mode(int fused, int rows_per_seg);
+
 /* ---- conv + folded BN (+ residual) (+ ReLU) (resnets_shift.py:49-65, 19-27) -------------------
  * in_pf: PF (h_in, w_in, cin); out_pf / resid_pf: PF (h_in/stride, w_in/stride, cout).
  * resid_pf may be NULL.  in_pf must not alias out_pf. */
@@ -105,6 +110,10 @@ int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const ui
                       int n, int h, int w, void* workspace, float* feat_out /* [n][512] or NULL */,
                       float* logits_out /* [n][head_k] or NULL */, float* fmap_out /* f32 NCHW [n][512][h/32][w/32] or NULL */,
                       void* stream);
+/* Sub-batching of the early (large-map) stages so their tensors stay in the 256 MiB Infinity Cache:
+ * stem+maxpool run `stem_chunk` images at a time, layer1 `layer1_chunk` (a multiple of stem_chunk);
+ * 0 = whole batch (default; measured on MI355X: sub-batching gives no gain at batch 500).  Process-wide. */
+int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk);
 /* debug / parity taps: run the trunk up to stage `stop_after` (0 = stem+maxpool output, 1..8 =
  * layer1.0, layer1.1, ..., layer4.1) and unpack that tensor to f32 NCHW. */
 int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,

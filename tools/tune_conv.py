@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsi_segmentation_pipeline_amd import engine as E, native  # noqa: E402
 
 SHAPES = [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]      # (C, H, W) for 256x256 patches
-NCFG = 10
+NCFG = 28
 
 
 def main():
@@ -23,6 +23,9 @@ def main():
     ap.add_argument('--planes', type=int, default=2)
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--cfgs', type=str, default='')
+    ap.add_argument('--ablate', type=str, default='1', help='comma list of relu/ablation bit masks')
+    ap.add_argument('--noresid', action='store_true')
     ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
     args = ap.parse_args()
     lib = native.load()
@@ -40,27 +43,37 @@ def main():
         outs = {cfg: E.pf_zeros(n, c, h, w, args.planes, dev) for cfg in range(NCFG)}
         flops = 2.0 * n * h * w * c * c * 9
 
+        flag = [1]
+
         def run(cfg):
-            return lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), outs[cfg].data_ptr(), rpf.data_ptr(), wpk.data_ptr(), bias.data_ptr(),
-                                              n, h, w, c, c, 1, 1, args.planes, cfg, st())
-        valid = [cfg for cfg in range(NCFG) if run(cfg) == 0]
+            return lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), outs[cfg].data_ptr(), None if args.noresid else rpf.data_ptr(),
+                                              wpk.data_ptr(), bias.data_ptr(), n, h, w, c, c, 1, flag[0], args.planes, cfg, st())
+        want = [int(v) for v in args.cfgs.split(',')] if args.cfgs else list(range(NCFG))
+        valid = [cfg for cfg in want if run(cfg) == 0]
         torch.cuda.synchronize()
+        if not valid:
+            continue
         ref = outs[valid[0]]
         same = {cfg: bool(torch.equal(outs[cfg], ref)) for cfg in valid}
+        masks = [int(v) for v in args.ablate.split(',')]
+        valid = [(cfg, mk) for cfg in valid for mk in masks]
         times = {cfg: [] for cfg in valid}
+        same = {k: same[k[0]] for k in valid}
         for _ in range(args.rounds):
             for cfg in valid:
+                flag[0] = cfg[1]
+                cfg_id = cfg[0]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
-                    run(cfg)
+                    run(cfg_id)
                 e1.record()
                 torch.cuda.synchronize()
                 times[cfg].append(e0.elapsed_time(e1) / args.iters)
         print('shape C=%d %dx%d n=%d planes=%d  (%.1f GFLOP)' % (c, h, w, n, args.planes, flops / 1e9))
         for cfg in valid:
             med, mn = float(np.median(times[cfg])), float(np.min(times[cfg]))
-            print('  cfg %d: median %.3f ms  min %.3f ms  -> %.1f TFLOP/s algorithmic  identical=%s' %
+            print('  cfg %s: median %.3f ms  min %.3f ms  -> %.1f TFLOP/s algorithmic  identical=%s' %
                   (cfg, med, mn, flops / med / 1e9, same[cfg]))
 
 

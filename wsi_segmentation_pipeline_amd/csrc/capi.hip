@@ -8,6 +8,7 @@
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
 int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st);
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
                             float* logits, int planes, hipStream_t st);
 int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
@@ -143,6 +144,14 @@ int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_ou
 }
 
 // ------------------------------------------------------------------------------------ single ops
+static int g_stem_fused = 1, g_stem_rows = 16;       // fused stem+maxpool kernel; pooled rows per workgroup
+
+int wsi_stem_set_mode(int fused, int rows_per_seg) {
+    if (rows_per_seg <= 0) return WSI_EINVAL;
+    g_stem_fused = fused ? 1 : 0; g_stem_rows = rows_per_seg;
+    return WSI_OK;
+}
+
 int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
                                      int slide_h, int slide_w, const int* tile_xy, const float* lut,
                                      const void* stem_wpk, const float* stem_bias, int n, int h, int w,
@@ -154,6 +163,7 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
     a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
     a.origins = tile_xy; a.lut = lut; a.wpk = stem_wpk; a.bias = stem_bias; a.out = scratch;
     a.N = n; a.H = h; a.W = w;
+    if (g_stem_fused) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
     return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
@@ -274,6 +284,14 @@ static inline int prof_open(hipStream_t st, int kind, double flops) {
 static inline void prof_close(hipStream_t st, int i) { if (i >= 0) (void)hipEventRecord(g_prof.ev[2 * i + 1], st); }
 
 // ------------------------------------------------------------------------------------ trunk
+static int g_chunk_stem = 0, g_chunk_l1 = 0;   // sub-batch sizes (images); 0 = whole batch (measured r01: no gain)
+
+int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk) {
+    if (stem_chunk < 0 || layer1_chunk < 0) return WSI_EINVAL;
+    if (stem_chunk && layer1_chunk && layer1_chunk % stem_chunk) return WSI_EINVAL;
+    g_chunk_stem = stem_chunk; g_chunk_l1 = layer1_chunk;
+    return WSI_OK;
+}
 struct TrunkPlan {
     size_t stem_scratch;          // byte offsets into the workspace
     size_t buf[4][3];
@@ -317,43 +335,72 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                      int stop_after, hipStream_t st, const TrunkPlan& p, size_t& last_off, int& last_stage) {
     char* ws = (char*)workspace;
     const int planes = wt->planes;
-    int rc;
-    {
-        const int pi_ = prof_open(st, 4, 2.0 * n * (h / 2) * (w / 2) * 64.0 * 147.0);
-        rc = wsi_stem_conv7x7_bn_relu_maxpool(in_f32, slide, pitch, slide_h, slide_w, tile_xy, lut, wt->stem_w, wt->stem_b, n,
-                                              h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0], planes, st);
-        prof_close(st, pi_);
-    }
-    if (rc) return rc;
-    last_off = p.buf[0][0]; last_stage = 0;
-    if (stop_after == 0) return WSI_OK;
-    // kind: 1 = 3x3 stride-1 (slab kernel), 2 = 3x3 stride-2 (gather), 3 = 1x1 downsample; flops = 2*M*N*K
-    // over real output pixels (padding taps counted)
-#define PROF_CONV(kind, HO, WO, CI, CO, KK, call)                                                    \
+    int rc = WSI_OK;
+    // kind: 1 = 3x3 stride-1 (slab kernel), 2 = 3x3 stride-2 (gather), 3 = 1x1 downsample, 4 = stem+maxpool;
+    // flops = 2*M*N*K over real output pixels (padding taps counted)
+#define PROF_CONV(kind, NN, HO, WO, CI, CO, KK, call)                                                \
     do {                                                                                            \
-        const int pi_ = prof_open(st, kind, 2.0 * n * (HO) * (WO) * (double)(CO) * (CI) * (KK));     \
+        const int pi_ = prof_open(st, kind, 2.0 * (NN) * (HO) * (WO) * (double)(CO) * (CI) * (KK));  \
         rc = (call);                                                                                \
         prof_close(st, pi_);                                                                        \
+        if (rc) return rc;                                                                          \
     } while (0)
-    int cur = 0;                                       // index of the buffer holding the stage input
-    const void* x = ws + p.buf[0][0];
-    int block = 0;
-    for (int s = 0; s < 4; ++s) {
+    // byte offset of image n0 inside a PF buffer of stage s
+    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * planes * 2; };
+
+    // ---- stem + maxpool + layer1 run in sub-batches so that the 4 MB/patch fp32 stem scratch and
+    //      the 1 MB/patch layer-1 tensors stay resident in the 256 MiB Infinity Cache; the deeper
+    //      (small-map) stages run on the whole batch to fill the chip.
+    const int cs = g_chunk_stem > 0 ? g_chunk_stem : n, c1 = g_chunk_l1 > 0 ? g_chunk_l1 : n;
+    const int H1 = p.sh[0], W1 = p.sw[0];
+    const int do_l1 = stop_after != 0;
+    int l1_out = 0;                                    // buffer index holding layer1's output
+    for (int n1 = 0; n1 < n; n1 += c1) {
+        const int nn1 = n - n1 < c1 ? n - n1 : c1;
+        for (int n0 = n1; n0 < n1 + nn1; n0 += cs) {
+            const int nn = n1 + nn1 - n0 < cs ? n1 + nn1 - n0 : cs;
+            const int pi_ = prof_open(st, 4, 2.0 * nn * (h / 2) * (w / 2) * 64.0 * 147.0);
+            rc = wsi_stem_conv7x7_bn_relu_maxpool(in_f32 ? in_f32 + (size_t)n0 * 3 * h * w : nullptr, slide, pitch, slide_h,
+                                                  slide_w, tile_xy ? tile_xy + 2 * n0 : nullptr, lut, wt->stem_w, wt->stem_b,
+                                                  nn, h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0] + img_off(0, n0),
+                                                  planes, st);
+            prof_close(st, pi_);
+            if (rc) return rc;
+        }
+        if (!do_l1) continue;
+        int cur = 0;
+        for (int b = 0; b < 2 && (stop_after >= 8 || b < stop_after); ++b) {
+            const int m = (cur + 1) % 3, o = (cur + 2) % 3;
+            char *x = ws + p.buf[0][cur] + img_off(0, n1), *mid = ws + p.buf[0][m] + img_off(0, n1),
+                 *out = ws + p.buf[0][o] + img_off(0, n1);
+            PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
+                                                                     H1, W1, 64, 64, 1, 1, planes, st));
+            PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
+                                                                     nn1, H1, W1, 64, 64, 1, 1, planes, st));
+            cur = o;
+        }
+        l1_out = cur;
+    }
+    last_off = p.buf[0][l1_out]; last_stage = 0;
+    if (stop_after >= 0 && stop_after <= 2) return WSI_OK;
+
+    int cur = l1_out;
+    const void* x = ws + p.buf[0][cur];
+    int block = 2;
+    for (int s = 1; s < 4; ++s) {
         const int H = p.sh[s], W = p.sw[s], C = p.sc[s];
         for (int b = 0; b < 2; ++b) {
             const int wi = s * 4 + b * 2;
             void *mid, *out;
             const void* resid;
-            if (s > 0 && b == 0) {                     // strided block with 1x1 downsample branch
+            if (b == 0) {                              // strided block with 1x1 downsample branch
                 mid = ws + p.buf[s][1];
                 void* ds = ws + p.buf[s][2];
                 out = ws + p.buf[s][0];
-                PROF_CONV(2, H, W, C / 2, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, 2 * H,
-                                                                  2 * W, C / 2, C, 2, 1, planes, st));
-                if (rc) return rc;
-                PROF_CONV(3, H, W, C / 2, C, 1, wsi_conv1x1_bn(x, ds, wt->down_w[s - 1], wt->down_b[s - 1], n, 2 * H, 2 * W,
-                                                              C / 2, C, 2, planes, st));
-                if (rc) return rc;
+                PROF_CONV(2, n, H, W, C / 2, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, 2 * H,
+                                                                     2 * W, C / 2, C, 2, 1, planes, st));
+                PROF_CONV(3, n, H, W, C / 2, C, 1, wsi_conv1x1_bn(x, ds, wt->down_w[s - 1], wt->down_b[s - 1], n, 2 * H, 2 * W,
+                                                                 C / 2, C, 2, planes, st));
                 resid = ds;
                 cur = 0;
                 last_off = p.buf[s][0];
@@ -361,16 +408,14 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 const int m = (cur + 1) % 3, o = (cur + 2) % 3;
                 mid = ws + p.buf[s][m];
                 out = ws + p.buf[s][o];
-                PROF_CONV(1, H, W, C, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, H, W, C, C,
-                                                              1, 1, planes, st));
-                if (rc) return rc;
+                PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, H, W, C, C,
+                                                                 1, 1, planes, st));
                 resid = x;
                 cur = o;
                 last_off = p.buf[s][o];
             }
-            PROF_CONV(1, H, W, C, C, 9, wsi_conv3x3_bn_act(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C,
-                                                          C, 1, 1, planes, st));
-            if (rc) return rc;
+            PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C,
+                                                             C, 1, 1, planes, st));
             x = out;
             ++block;
             last_stage = s;

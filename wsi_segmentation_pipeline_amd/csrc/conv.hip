@@ -22,34 +22,54 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
                                                      int lane) {
     const int l31 = lane & 31, h = lane >> 5;
     const size_t pixstride = (size_t)a.go.C * PLANES * 2;
+    const size_t chan_off = (size_t)ntile * (64 * PLANES) + (size_t)(4 * h) * 2;
+    bool valid[MT];
+    size_t poff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = q_base + mt * 32 + l31;
+        valid[mt] = pf_is_pixel(a.go, q);
+        poff[mt] = (size_t)(valid[mt] ? q : a.go.G) * pixstride + chan_off;     // pad rows read a real pixel, store nothing
+    }
+    // phase 1: every residual load of the tile in flight at once (branch-free)
+    bf16x4 rh[MT][4], rl[MT][4];
+    if (a.resid) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const char* rp = (const char*)a.resid + poff[mt] + 16 * g;
+                if (a.relu & 256) {
+                    rh[mt][g] = __builtin_nontemporal_load((const bf16x4*)rp);
+                    if constexpr (PLANES == 2) rl[mt][g] = __builtin_nontemporal_load((const bf16x4*)(rp + 64));
+                } else {
+                    rh[mt][g] = *(const bf16x4*)rp;
+                    if constexpr (PLANES == 2) rl[mt][g] = *(const bf16x4*)(rp + 64);
+                }
+            }
+    }
     float bias[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
+    // phase 2: bias + residual + ReLU, split, store
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int q = q_base + mt * 32 + l31;
-        if (!pf_is_pixel(a.go, q)) continue;
-        char* opix = (char*)a.out + (size_t)q * pixstride + (size_t)ntile * (64 * PLANES);
-        const char* rpix = a.resid ? (const char*)a.resid + (size_t)q * pixstride + (size_t)ntile * (64 * PLANES) : nullptr;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int coff = (8 * g + 4 * h) * 2;
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = acc[mt][4 * g + i] + bias[4 * g + i];
-            if (rpix) {
-                bf16x4 rh = *(const bf16x4*)(rpix + coff);
+            if (a.resid) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += (float)rh[i];
+                for (int i = 0; i < 4; ++i) v[i] += (float)rh[mt][g][i];
                 if constexpr (PLANES == 2) {
-                    bf16x4 rl = *(const bf16x4*)(rpix + 64 + coff);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)rl[i];
+                    for (int i = 0; i < 4; ++i) v[i] += (float)rl[mt][g][i];
                 }
             }
-            if (a.relu) {
+            if (a.relu & 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
             }
@@ -59,31 +79,45 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
                 hi[i] = (__bf16)v[i];
                 lo[i] = (__bf16)(v[i] - (float)hi[i]);
             }
-            *(bf16x4*)(opix + coff) = hi;
-            if constexpr (PLANES == 2) *(bf16x4*)(opix + 64 + coff) = lo;
+            if (valid[mt] && !(a.relu & 2)) {
+                char* op = (char*)a.out + poff[mt] + 16 * g;
+                if (a.relu & 256) {
+                    __builtin_nontemporal_store(hi, (bf16x4*)op);
+                    if constexpr (PLANES == 2) __builtin_nontemporal_store(lo, (bf16x4*)(op + 64));
+                } else {
+                    *(bf16x4*)op = hi;
+                    if constexpr (PLANES == 2) *(bf16x4*)(op + 64) = lo;
+                }
+            }
         }
     }
 }
 
-// One 128-byte line of K for MT pixel tiles: 4 fragments per operand.
+// One 128-byte line of K for MT pixel tiles: 4 fragments per operand; the pixel fragments of tile
+// mt+1 are requested before the MFMAs of tile mt so the LDS latency hides behind them.
 template <int MT, int PLANES>
 static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8 (&wf)[4], const char* smem,
                                                  const int (&xbase)[MT]) {
+    bf16x8 xf[2][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) xf[0][f] = *(const bf16x8*)(smem + (xbase[0] ^ (f << 5)));
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        bf16x8 xf[4];
+        const bf16x8(&x)[4] = xf[mt & 1];
+        if (mt + 1 < MT) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) xf[f] = *(const bf16x8*)(smem + (xbase[mt] ^ (f << 5)));
+            for (int f = 0; f < 4; ++f) xf[(mt + 1) & 1][f] = *(const bf16x8*)(smem + (xbase[mt + 1] ^ (f << 5)));
+        }
         if constexpr (PLANES == 2) {
-            acc[mt] = mfma_bf16(wf[2], xf[0], acc[mt]);   // lo*hi
-            acc[mt] = mfma_bf16(wf[3], xf[1], acc[mt]);
-            acc[mt] = mfma_bf16(wf[0], xf[2], acc[mt]);   // hi*lo
-            acc[mt] = mfma_bf16(wf[1], xf[3], acc[mt]);
-            acc[mt] = mfma_bf16(wf[0], xf[0], acc[mt]);   // hi*hi
-            acc[mt] = mfma_bf16(wf[1], xf[1], acc[mt]);
+            acc[mt] = mfma_bf16(wf[2], x[0], acc[mt]);   // lo*hi
+            acc[mt] = mfma_bf16(wf[3], x[1], acc[mt]);
+            acc[mt] = mfma_bf16(wf[0], x[2], acc[mt]);   // hi*lo
+            acc[mt] = mfma_bf16(wf[1], x[3], acc[mt]);
+            acc[mt] = mfma_bf16(wf[0], x[0], acc[mt]);   // hi*hi
+            acc[mt] = mfma_bf16(wf[1], x[1], acc[mt]);
         } else {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(wf[f], xf[f], acc[mt]);
+            for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(wf[f], x[f], acc[mt]);
         }
     }
 }
@@ -140,7 +174,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab_kernel(ConvA
 #pragma unroll
         for (int f = 0; f < 4; ++f) wcur[f] = wp[f * 64];     // tap 0 weights fly during the slab DMA
         if (c) __syncthreads();                               // every wave is done reading the previous line
-        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
+        for (int i0 = wave * 64; i0 < ((a.relu & 4) ? 0 : npieces); i0 += NTHREADS) {
             const int i = i0 + lane;
             const int Pl = i >> 3, sp = i & 7;
             const int s = sp ^ ((Pl >> 1) & 7);
@@ -150,15 +184,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab_kernel(ConvA
         __syncthreads();
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
-            if (t < 8) {
+            if (t < 8 && !(a.relu & 16)) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) wnxt[f] = wp[((t + 1) * 4 + f) * 64];
+                for (int f = 0; f < 4; ++f) wnxt[f] = ((a.relu & 32) ? wbase : wp)[(((a.relu & 32) ? 0 : t + 1) * 4 + f) * 64];
             }
             const int toff = (t / 3 - 1) * P + (t % 3 - 1) + P + 1;
             int xbase[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(xoff[mt] + toff, h);
-            mfma_line<MT, PLANES>(acc, wcur, smem, xbase);
+            if (!(a.relu & 8)) mfma_line<MT, PLANES>(acc, wcur, smem, xbase);
 #pragma unroll
             for (int f = 0; f < 4; ++f) wcur[f] = wnxt[f];
         }
@@ -241,6 +275,247 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
+// Slab kernel, pipelined form: two slab buffers; the DMA of line c+1 is issued during tap 0 of line
+// c and has two taps of MFMA work to land; ONE raw barrier per line.  Weight fragments are loaded
+// by inline asm (invisible to hipcc's waitcnt pass, so they do not drain the DMA) and retired by
+// hand-counted s_waitcnt vmcnt: VMEM issue order per line is  W(1), DMA(c+1) x ND, W(2), W(3)...
+//   tap 1 needs W(1): everything younger is the ND DMA pieces      -> vmcnt(ND)
+//   every other tap needs the newest load                           -> vmcnt(0)
+static __device__ __forceinline__ void wload4(bf16x8 (&w)[4], const bf16x8* p) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %4, off offset:1024\n\t"
+        "global_load_dwordx4 %2, %4, off offset:2048\n\t"
+        "global_load_dwordx4 %3, %4, off offset:3072"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+        : "v"(p)
+        : "memory");
+}
+#define WWAIT(N, w) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory")
+static __device__ __forceinline__ void wwait_n(int nd, bf16x8 (&w)[4]) {
+    switch (nd) {                       // wave-uniform
+        case 0: WWAIT(0, w); break;
+        case 1: WWAIT(1, w); break;
+        case 2: WWAIT(2, w); break;
+        case 3: WWAIT(3, w); break;
+        case 4: WWAIT(4, w); break;
+        case 5: WWAIT(5, w); break;
+        case 6: WWAIT(6, w); break;
+        case 7: WWAIT(7, w); break;
+        case 8: WWAIT(8, w); break;
+        case 9: WWAIT(9, w); break;
+        case 10: WWAIT(10, w); break;
+        case 11: WWAIT(11, w); break;
+        case 12: WWAIT(12, w); break;
+        default: WWAIT(0, w); break;
+    }
+}
+
+template <int MT, int WM, int WN, int PLANES, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab2_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MT * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    const int nb = blockIdx.x % nblocks;
+    const int mtile = blockIdx.x / nblocks;
+    const int P = a.gi.P;
+    const int q0 = a.gi.G + mtile * BM;
+    const int npieces = (BM + 2 * P + 2) * 8;
+    const int nd = __builtin_amdgcn_readfirstlane((npieces - wave * 64 + NTHREADS - 1) / NTHREADS);   // DMA instrs per wave per line
+    const int bufbytes = (npieces + NTHREADS - 1) / NTHREADS * NTHREADS * 16;
+    const int ntile = nb * WN + wn;
+    const int NC = a.gi.C * PLANES / 64;
+    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
+    const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * 9 * 4 * 64 + lane;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    int xoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
+
+    auto stage = [&](int c, char* buf) {
+        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
+            const int i = i0 + lane;
+            const int Pl = i >> 3, sp = i & 7;
+            const int s = sp ^ ((Pl >> 1) & 7);
+            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16, buf + (size_t)i0 * 16);
+        }
+    };
+
+    bf16x8 wcur[4], wnxt[4];
+    wload4(wnxt, wbase);                                      // W(0,0)
+    stage(0, smem);
+    for (int c = 0; c < NC; ++c) {
+        const char* buf = smem + (c & 1) * bufbytes;
+        // line c's slab: own DMA pieces retired (vmcnt(0) also retires W(c,0)), then everyone's
+        WWAIT(0, wnxt);
+        __builtin_amdgcn_s_barrier();
+        const bf16x8* wp = wbase + (size_t)c * 9 * 4 * 64;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            if (t == 1) wwait_n(c + 1 < NC ? nd : 0, wnxt);
+            else if (t > 1) WWAIT(0, wnxt);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) wcur[f] = wnxt[f];
+            if (t < 8) wload4(wnxt, wp + (size_t)(t + 1) * 4 * 64);
+            else if (c + 1 < NC) wload4(wnxt, wp + (size_t)9 * 4 * 64);
+            if (t == 0 && c + 1 < NC) stage(c + 1, smem + ((c + 1) & 1) * bufbytes);
+            const int toff = (t / 3 - 1) * P + (t % 3 - 1) + P + 1;
+            int xbase[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(xoff[mt] + toff, h);
+            mfma_line<MT, PLANES>(acc, wcur, buf, xbase);
+        }
+    }
+    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+}
+
+template <int MT, int WM, int WN, int PLANES, int MINW>
+static int launch_slab2(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
+    if (a.go.C % (WN * 32)) return WSI_EINVAL;
+    const int mtiles = (a.gi.NS + BM - 1) / BM;
+    const int nblocks = a.go.C / (WN * 32);
+    const int npieces = (BM + 2 * a.gi.P + 2) * 8;
+    if ((npieces + NTHREADS - 1) / NTHREADS > 12) return WSI_EINVAL;     // wwait_n table
+    const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16 * 2;
+    if (lds > 160 * 1024) return WSI_EINVAL;
+    auto k = conv3x3s1_slab2_kernel<MT, WM, WN, PLANES, MINW>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return WSI_EINVAL;
+    }
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+// --------------------------------------------------------------------------------------------
+// Slab kernel, software-pipelined form.  Per 128-byte line the nine taps are straight-line code:
+//   * weight fragments come through buffer loads (scalar offset per tap, no address VALU) into a
+//     3-slot register ring indexed statically (tap % 3): no copies, prefetch distance one tap;
+//   * pixel fragments are requested one (tap, m-tile) step ahead - including across taps - so the
+//     LDS latency always hides behind six MFMAs;
+//   * a compiler scheduling fence per tap keeps hipcc from hoisting all nine taps' loads.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int MT, int WM, int WN, int PLANES, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MT * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (a.relu & 64) return;                                  // ablation: dispatch cost only
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    const int nb = blockIdx.x % nblocks;                      // b % 8 picks the XCD: one channel block per XCD for nblocks | 8
+    const int mtile = blockIdx.x / nblocks;
+    const int P = a.gi.P;
+    const int q0 = a.gi.G + mtile * BM;
+    const int npieces = (BM + 2 * P + 2) * 8;
+    const int ntile = nb * WN + wn;
+    const int NC = (a.relu & 128) ? 0 : a.gi.C * PLANES / 64;  // ablation: no main loop, epilogue only
+    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
+    const int wvoff = lane * 16;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    int xoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
+
+    auto wload = [&](bf16x8(&w)[4], int soff) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            w[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + f * 1024, soff, 0));
+    };
+    auto xload = [&](bf16x8(&x)[4], int Pl) {
+        const int base = lds_xbase(Pl, h);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+    };
+
+    for (int c = 0; c < NC; ++c) {
+        const int sline = c * 9 * 4096;
+        int Pc = P;                                           // opaque per line: stops LICM from keeping all
+        asm volatile("" : "+s"(Pc));                          // 36 tap/tile LDS addresses live in registers
+        bf16x8 wbuf[3][4], xf[2][4];
+        wload(wbuf[0], sline);                                // W(c,0) flies during the slab DMA
+        if (c) __syncthreads();
+        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
+            const int i = i0 + lane;
+            const int Pl = i >> 3, sp = i & 7;
+            const int s = sp ^ ((Pl >> 1) & 7);
+            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16, smem + (size_t)i0 * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        xload(xf[0], xoff[0]);                                // step (t=0, mt=0): toff(0) = 0
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            asm volatile("" ::: "memory");                    // scheduling fence: keep later taps' loads below
+            if (t < 8) wload(wbuf[(t + 1) % 3], sline + (t + 1) * 4096);
+            const int toff = (t / 3) * Pc + (t % 3);
+            const int toff_next = ((t + 1) / 3) * Pc + ((t + 1) % 3);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int k = t * MT + mt;
+                if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
+                else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                const bf16x8(&w)[4] = wbuf[t % 3];
+                const bf16x8(&x)[4] = xf[k & 1];
+                if constexpr (PLANES == 2) {
+                    acc[mt] = mfma_bf16(w[2], x[0], acc[mt]);   // lo*hi
+                    acc[mt] = mfma_bf16(w[3], x[1], acc[mt]);
+                    acc[mt] = mfma_bf16(w[0], x[2], acc[mt]);   // hi*lo
+                    acc[mt] = mfma_bf16(w[1], x[3], acc[mt]);
+                    acc[mt] = mfma_bf16(w[0], x[0], acc[mt]);   // hi*hi
+                    acc[mt] = mfma_bf16(w[1], x[1], acc[mt]);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(w[f], x[f], acc[mt]);
+                }
+            }
+        }
+    }
+    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+}
+
+template <int MT, int WM, int WN, int PLANES, int MINW>
+static int launch_slab3(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
+    if (a.go.C % (WN * 32)) return WSI_EINVAL;
+    const int mtiles = (a.gi.NS + BM - 1) / BM;
+    const int nblocks = a.go.C / (WN * 32);
+    const int npieces = (BM + 2 * a.gi.P + 2) * 8;
+    size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    if (lds > 160 * 1024) return WSI_EINVAL;
+    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return WSI_EINVAL;
+    }
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
 template <int MT, int WM, int WN, int PLANES, int MINW>
 static int launch_slab(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
@@ -284,8 +559,36 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(8, 4, 4, 2, 2)  \
     X(9, 4, 1, 2, 2)
 
+// pipelined (double-buffered) variants: cfg 10 + index
+#define SLAB2_CFGS(X) \
+    X(10, 4, 1, 4, 2) \
+    X(11, 4, 2, 2, 2) \
+    X(12, 8, 1, 4, 2) \
+    X(13, 4, 1, 2, 2) \
+    X(14, 8, 1, 2, 2) \
+    X(15, 2, 2, 4, 2)
+
+// software-pipelined variants: cfg 20 + index
+#define SLAB3_CFGS(X) \
+    X(20, 4, 1, 4, 2) \
+    X(21, 4, 2, 2, 2) \
+    X(22, 4, 1, 4, 3) \
+    X(23, 4, 2, 2, 3) \
+    X(24, 8, 1, 4, 2) \
+    X(25, 2, 2, 4, 3) \
+    X(26, 4, 1, 2, 3) \
+    X(27, 8, 2, 2, 2)
+
 int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     switch (cfg) {
+#define X(id, MT, WM, WN, MINW) \
+    case id: return planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW>(a, st) : launch_slab3<MT, WM, WN, 1, MINW>(a, st);
+        SLAB3_CFGS(X)
+#undef X
+#define X(id, MT, WM, WN, MINW) \
+    case id: return planes == 2 ? launch_slab2<MT, WM, WN, 2, MINW>(a, st) : launch_slab2<MT, WM, WN, 1, MINW>(a, st);
+        SLAB2_CFGS(X)
+#undef X
 #define X(id, MT, WM, WN, MINW) \
     case id: return planes == 2 ? launch_slab<MT, WM, WN, 2, MINW>(a, st) : launch_slab<MT, WM, WN, 1, MINW>(a, st);
         SLAB_CFGS(X)
@@ -295,7 +598,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st
 }
 
 // default config per layer shape (tuned on MI355X, tools/tune_conv.py)
-static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 2 : 3; }   // r01 tune: profiles/r01_tune_conv.log
+static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 20 : 21; }   // r01 tune: profiles/r01_tune_conv*.log
 
 // Host dispatch.  cfg < 0 selects the tuned default.
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {

@@ -167,6 +167,176 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* in, void
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Fused stem: tile read + LUT normalise + conv7x7 s2 + BN + ReLU + maxpool 3x3 s2 -> PF planes.
+// The 4 MB/patch fp32 conv output never exists.  Work split:
+//   workgroup = 2 waves = one strip of 15 pooled columns (31 conv columns: ONE MFMA pixel tile,
+//   lane = conv column) x one segment of pooled rows; wave w owns output channels 32w..32w+31 and
+//   keeps that slice of the packed weights in registers (14 k-steps x planes).
+//   Per pooled row the wave computes the two new conv rows (2py, 2py+1); the vertical max with the
+//   carried row 2py-1 is register-local, the horizontal 3-max is two lane shuffles, results sit on
+//   odd lanes.  The normalised input lives in a 16-row LDS ring: 4 new rows are staged per step,
+//   one barrier per step.
+struct StemPoolArgs {
+    StemArgs s;              // s.out unused
+    void* out_pf;            // PF (H/4, W/4, 64)
+    int rows_per_seg;        // pooled rows per workgroup
+};
+
+constexpr int SP_COLS = 68;                  // input columns per strip (2*31 + 6)
+constexpr int SP_RING = 16;                  // ring rows
+constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
+
+template <int PLANES>
+__global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const StemArgs& a = A.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = output-channel tile
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Hc = a.H / 2, Wc = a.W / 2, Hp = a.H / 4, Wp = a.W / 4;
+    const int nstrips = (Wp + 14) / 15, nsegs = (Hp + A.rows_per_seg - 1) / A.rows_per_seg;
+    int b = blockIdx.x;
+    const int strip = b % nstrips; b /= nstrips;
+    const int seg = b % nsegs;
+    const int n = b / nsegs;
+    const int px0 = strip * 15, c0 = 2 * px0 - 1;                       // first pooled col / first conv col (lane 0)
+    const int py0 = seg * A.rows_per_seg;
+    const int py1 = min(py0 + A.rows_per_seg, Hp);
+    const int ix0 = 2 * c0 - 3;                                         // input column of LDS column 0
+    int tx = 0, ty = 0;
+    if (a.mode == 1) { tx = a.origins[2 * n]; ty = a.origins[2 * n + 1]; }
+
+    // this wave's weights: [nt][ks][plane][lane][8] -> registers
+    bf16x8 wreg[14][PLANES];
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p)
+            wreg[ks][p] = *((const bf16x8*)a.wpk + ((size_t)(wave * 14 + ks) * PLANES + p) * 64 + lane);
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = a.bias[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
+
+    auto stage_rows = [&](int row_lo, int nrows) {                      // input rows [row_lo, row_lo+nrows) -> ring
+        for (int i = tid; i < nrows * SP_COLS; i += 128) {
+            const int r = i / SP_COLS, cc = i - r * SP_COLS;
+            const int iy = row_lo + r, ix = ix0 + cc;
+            float v[3] = {0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                if (a.mode == 0) {
+                    const size_t base = ((size_t)n * 3 * a.H + iy) * a.W + ix;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = a.in_f32[base + (size_t)c * a.H * a.W];
+                } else {
+                    const int sx = tx + ix, sy = ty + iy;
+                    uint8_t px[3] = {0, 0, 0};
+                    if (sx >= 0 && sx < a.SW && sy >= 0 && sy < a.SH) {
+                        const uint8_t* pp = a.slide + (size_t)sy * a.slide_pitch + (size_t)sx * 3;
+                        px[0] = pp[0]; px[1] = pp[1]; px[2] = pp[2];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] = a.lut[c * 256 + px[c]];
+                }
+            }
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { hi[c] = (__bf16)v[c]; lo[c] = (__bf16)(v[c] - (float)hi[c]); }
+            hi[3] = (__bf16)0.f; lo[3] = (__bf16)0.f;
+            const int slot = (iy + 64) & (SP_RING - 1);
+            *(bf16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = hi;
+            if constexpr (PLANES == 2) *(bf16x4*)(smem + SP_PLANE + (size_t)(slot * SP_COLS + cc) * 8) = lo;
+        }
+    };
+
+    // the first step is py0-1: it only produces the carried conv row 2*py0-1 (all zero for py0 == 0)
+    stage_rows(4 * (py0 - 1) - 3, 9);
+    __syncthreads();
+    float carry[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+    const bool col_ok = (c0 + l31) >= 0 && (c0 + l31) < Wc && l31 < 31;
+    const int lc = l31 < 31 ? l31 : 30;                                 // lane 31 is idle: keep its reads inside the row
+    const size_t pixstride = (size_t)64 * PLANES * 2;
+    PFGeom go = pf_geom(a.N, Hp, Wp, 64);
+
+    for (int py = py0 - 1; py < py1; ++py) {
+        if (py + 1 < py1) stage_rows(4 * (py + 1) + 2, 4);             // rows the NEXT step adds (not read by this step)
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            const int kh = ks >> 1, kw0 = (ks & 1) * 4 + 2 * h;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int slot = (4 * py + 2 * mt - 3 + kh + 64) & (SP_RING - 1);
+                const char* xp = smem + (size_t)(slot * SP_COLS + 2 * lc + kw0) * 8;
+                const bf16x8 x0 = *(const bf16x8*)xp;
+                if constexpr (PLANES == 2) {
+                    const bf16x8 x1 = *(const bf16x8*)(xp + SP_PLANE);
+                    acc[mt] = mfma_bf16(wreg[ks][1], x0, acc[mt]);
+                    acc[mt] = mfma_bf16(wreg[ks][0], x1, acc[mt]);
+                }
+                acc[mt] = mfma_bf16(wreg[ks][0], x0, acc[mt]);
+            }
+        }
+        // bias + ReLU + validity mask, vertical max with the carried row, keep row 2py+1 as the next carry
+        const bool r0_ok = (2 * py) >= 0 && (2 * py) < Hc, r1_ok = (2 * py + 1) >= 0 && (2 * py + 1) < Hc;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a0 = (col_ok && r0_ok) ? fmaxf(acc[0][r] + bias[r], 0.f) : 0.f;
+            const float a1 = (col_ok && r1_ok) ? fmaxf(acc[1][r] + bias[r], 0.f) : 0.f;
+            v[r] = fmaxf(fmaxf(carry[r], a0), a1);
+            carry[r] = a1;
+        }
+        if (py >= py0) {
+            // horizontal 3-max: pooled column px0+j sits on odd lane 2j+1 of each 32-lane half
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], fmaxf(__shfl_up(v[r], 1), __shfl_down(v[r], 1)));
+            const int j = (l31 - 1) >> 1, px = px0 + j;
+            if ((l31 & 1) && l31 <= 29 && px < Wp) {
+                char* o = (char*)A.out_pf + (size_t)(go.G + n * go.S + py * go.P + px) * pixstride;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        hi[i] = (__bf16)v[4 * g + i];
+                        lo[i] = (__bf16)(v[4 * g + i] - (float)hi[i]);
+                    }
+                    const int c = wave * 32 + 8 * g + 4 * h;
+                    if constexpr (PLANES == 2) {
+                        *(bf16x4*)(o + wave * 128 + (8 * g + 4 * h) * 2) = hi;
+                        *(bf16x4*)(o + wave * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
+                    } else {
+                        *(bf16x4*)(o + c * 2) = hi;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                // next rows staged, this step's reads done
+    }
+}
+
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st) {
+    if (a.H % 4 || a.W % 4 || a.N <= 0 || (planes != 1 && planes != 2) || rows_per_seg <= 0) return WSI_EINVAL;
+    StemPoolArgs A;
+    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg;
+    const int Hp = a.H / 4, Wp = a.W / 4;
+    const long long grid = (long long)a.N * ((Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);
+    if (grid > 0x7fffffffLL) return WSI_EINVAL;
+    const size_t lds = (size_t)planes * SP_PLANE;
+    if (planes == 2)
+        hipLaunchKernelGGL(stem_pool_kernel<2>, dim3((int)grid), dim3(128), lds, st, A);
+    else
+        hipLaunchKernelGGL(stem_pool_kernel<1>, dim3((int)grid), dim3(128), lds, st, A);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st) {
     if (a.H % 16 || a.W % 2 || a.N <= 0 || (planes != 1 && planes != 2)) return WSI_EINVAL;
     const int Hc = a.H / 2, Wc = a.W / 2;

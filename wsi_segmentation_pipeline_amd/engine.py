@@ -22,8 +22,8 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(st=None):
+    return C.c_void_p((st or torch.cuda.current_stream()).cuda_stream)
 
 
 def _f32(sd, key):
@@ -54,7 +54,7 @@ class TrunkEngine:
     """
 
     def __init__(self, state_dict, device, planes=PARITY, head=None, max_batch=256,
-                 mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+                 mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), streams=1):
         self.lib = native.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -63,6 +63,9 @@ class TrunkEngine:
             raise ValueError('planes must be 1 (speed) or 2 (parity)')
         self.planes = planes
         self.max_batch = int(max_batch)
+        # batches of one call are spread round-robin over `streams` HIP streams (own workspace each), so a
+        # memory-bound stage of one batch overlaps an MFMA-bound stage of another and grid tails get filled
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(streams)))] if streams > 1 else []
         self._keep = []                          # device tensors referenced by raw pointers
         self._ws = {}
         self.wt = native.WsiTrunkWeights()
@@ -124,8 +127,8 @@ class TrunkEngine:
         self.wt.head_w, self.wt.head_b, self.wt.head_k = w.data_ptr(), b.data_ptr(), int(w.shape[0])
         self.head_k = int(w.shape[0])
 
-    def _workspace(self, n, h, w):
-        key = (n, h, w)
+    def _workspace(self, n, h, w, slot=0):
+        key = (n, h, w, slot)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = self.lib.wsi_trunk_workspace_bytes(n, h, w, self.planes)
@@ -134,14 +137,14 @@ class TrunkEngine:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             native.check(self.lib.wsi_trunk_workspace_init(_ptr(ws), n, h, w, self.planes, _stream()),
                          'wsi_trunk_workspace_init')
-            if len(self._ws) >= 4:                    # keep the plan cache small
+            if len(self._ws) >= 4 * max(1, len(self._streams)):   # keep the plan cache small
                 self._ws.pop(next(iter(self._ws)))
             self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ forward passes
-    def _run(self, n, h, w, in_f32, slide, tile_xy, want_feat, want_logits, want_fmap, tap=None):
-        ws = self._workspace(n, h, w)
+    def _run(self, n, h, w, in_f32, slide, tile_xy, want_feat, want_logits, want_fmap, tap=None, slot=0):
+        ws = self._workspace(n, h, w, slot)
         dev = self.device
         feat = torch.empty((n, 512), dtype=torch.float32, device=dev) if want_feat else None
         logits = torch.empty((n, self.head_k), dtype=torch.float32, device=dev) if want_logits else None
@@ -176,9 +179,7 @@ class TrunkEngine:
         n, _, h, w = x.shape
         if tap is not None:
             return self._run(n, h, w, x, None, None, False, False, False, tap)
-        outs = [self._run(min(self.max_batch, n - i), h, w, x[i:i + self.max_batch], None, None, feat, logits, fmap)
-                for i in range(0, n, self.max_batch)]
-        return tuple(None if o[0] is None else (o[0] if len(o) == 1 else torch.cat(o)) for o in zip(*outs))
+        return self._batched(n, lambda i, m, slot: self._run(m, h, w, x[i:i + m], None, None, feat, logits, fmap, slot=slot))
 
     def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
         """slide_u8: (SH,SW,3) uint8 GPU tensor (last two dims contiguous); tile_xy: (N,2) int32 GPU tensor of
@@ -194,8 +195,30 @@ class TrunkEngine:
         n = tile_xy.shape[0]
         if tap is not None:
             return self._run(n, ph, pw, None, slide_u8, tile_xy, False, False, False, tap)
-        outs = [self._run(min(self.max_batch, n - i), ph, pw, None, slide_u8, tile_xy[i:i + self.max_batch], feat, logits,
-                          fmap) for i in range(0, n, self.max_batch)]
+        return self._batched(n, lambda i, m, slot: self._run(m, ph, pw, None, slide_u8, tile_xy[i:i + m], feat, logits, fmap,
+                                                             slot=slot))
+
+    def _batched(self, n, run):
+        """Split n images into max_batch chunks; with several chunks, alternate them over the side streams."""
+        starts = list(range(0, n, self.max_batch))
+        if len(starts) == 1 or not self._streams:
+            outs = [run(i, min(self.max_batch, n - i), 0) for i in starts]
+        else:
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            outs = []
+            for j, i in enumerate(starts):
+                st = self._streams[j % len(self._streams)]
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    outs.append(run(i, min(self.max_batch, n - i), j % len(self._streams)))
+            for st in self._streams:
+                cur.wait_stream(st)
+            for o in outs:                                  # tensors were allocated on side streams
+                for t in o:
+                    if t is not None:
+                        t.record_stream(cur)
         return tuple(None if o[0] is None else (o[0] if len(o) == 1 else torch.cat(o)) for o in zip(*outs))
 
     # ------------------------------------------------------------------ small ops

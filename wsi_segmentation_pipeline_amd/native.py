@@ -40,6 +40,7 @@ SIGNATURES = {
     'wsi_prepack_stem': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     'wsi_normalize_u8_lut': (_i, [_vp, _vp, _vp]),
     'wsi_stem_conv7x7_bn_relu_maxpool': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'wsi_stem_set_mode': (_i, [_i, _i]),
     'wsi_conv3x3_bn_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_conv3x3_bn_act_cfg': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_conv1x1_bn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -51,6 +52,7 @@ SIGNATURES = {
     'wsi_trunk_workspace_init': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'wsi_trunk_forward': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'wsi_trunk_forward_tap': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'wsi_trunk_set_chunks': (_i, [_i, _i]),
     'wsi_prof_begin': (_i, [_i]),
     'wsi_prof_end': (_i, [_vp, _vp, _vp, _i]),
     'wsi_tile_gather': (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
