@@ -49,6 +49,8 @@ def main():
     ap.add_argument('--batch', type=int, default=500)
     ap.add_argument('--tiles', type=int, default=TILES_PER_GPU, help='tiles per GPU per step')
     ap.add_argument('--chunks', type=str, default='', help='stem_chunk,layer1_chunk sub-batch sizes (default: library default)')
+    ap.add_argument('--stem', type=str, default='', help='fused,rows_per_seg for the stem kernel (A/B)')
+    ap.add_argument('--s2', type=int, default=-1, help='1 = phase-slab stride-2 kernel with fused downsample, 0 = gather kernels (A/B)')
     ap.add_argument('--streams', type=int, default=1, help='batches in flight (HIP streams); >1 distorts per-kernel timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='disable per-launch HIP events (roofline leg)')
@@ -78,6 +80,11 @@ def main():
     if args.chunks:
         cs, c1 = (int(v) for v in args.chunks.split(','))
         native.check(lib.wsi_trunk_set_chunks(cs, c1), 'wsi_trunk_set_chunks')
+    if args.stem:
+        f, r = (int(v) for v in args.stem.split(','))
+        native.check(lib.wsi_stem_set_mode(f, r), 'wsi_stem_set_mode')
+    if args.s2 >= 0:
+        native.check(lib.wsi_conv_set_mode(args.s2), 'wsi_conv_set_mode')
     sd = W.make_resnet18_state_dict(11, with_fc=False)
     cls = W.make_head_state_dict(22, 'classifier')
     eng = TrunkEngine(sd, dev, planes=planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch,

@@ -61,7 +61,7 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
 
 /* tuning / A-B hook: fused = 1 (default) runs the single fused stem+maxpool kernel (no fp32
  * intermediate; scratch unused), fused = 0 the two-kernel form; rows_per_seg = pooled rows per
- * workgroup of the fused kernel (default 16).  Process-wide. */
+ * workgroup of the fused kernel (default 32).  Process-wide. */
 int wsi_stem_set_mode(int fused, int rows_per_seg);
 
 /* ---- conv + folded BN (+ residual) (+ ReLU) (resnets_shift.py:49-65, 19-27) -------------------
@@ -72,6 +72,15 @@ int wsi_conv3x3_bn_act(const void* in_pf, void* out_pf, const void* resid_pf, co
                        void* stream);
 int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,
                    int cin, int cout, int stride, int planes, void* stream);
+/* The two stride-2 convs of a downsampling BasicBlock in one pass over the input
+ * (resnets_shift.py:41 conv1 with stride 2 + ReLU, and :173-177 the 1x1 stride-2 downsample, no ReLU):
+ * out_conv_pf = relu(bn1(conv3x3_s2(x))), out_ds_pf = bn_d(conv1x1_s2(x)).  cout % 128 == 0. */
+int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf, const void* wpk3, const float* bias3,
+                           const void* wpk1, const float* bias1, int n, int h_in, int w_in, int cin, int cout, int planes,
+                           void* stream);
+/* A-B hook: s2_slab = 1 (default) routes stride-2 3x3 convs to the phase-slab kernel and lets the
+ * trunk fuse the downsample branch; 0 = per-tap gather kernel + separate 1x1 launch.  Process-wide. */
+int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */
 int wsi_conv3x3_bn_act_cfg(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,

@@ -165,3 +165,35 @@ def test_tile_gather_stitch_softmax(dev):
         assert (cls.cpu().numpy() != rc).mean() <= 1e-3           # ties under 1-ulp exp differences only
         rh = WO.tumorbed_heatmap(rp, mask, 'cls')
         assert np.abs(heat.cpu().numpy().astype(int) - rh.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 128, 16, 16), (2, 64, 128, 64, 64), (3, 128, 256, 32, 32), (5, 256, 512, 16, 16), (7, 256, 512, 4, 4)])
+def test_fused_stride2_block_entry(dev, shape):
+    """3x3 stride-2 conv (+ReLU) and the 1x1 stride-2 downsample in one launch == two separate convs."""
+    import ctypes as C
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    n, cin, cout, h, w = shape
+    lib = native.load()
+    for planes, tol in ((2, TOL_PARITY), (1, TOL_SPEED)):
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(n, cin, h, w, generator=g).abs_()
+        w3 = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        w1 = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+        bn3 = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1,
+               torch.rand(cout, generator=g) + 0.5)
+        bn1 = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1,
+               torch.rand(cout, generator=g) + 0.5)
+        ref3 = F.relu(F.batch_norm(F.conv2d(x, w3, None, 2, 1), bn3[2], bn3[3], bn3[0], bn3[1], False, 0.0, 1e-5))
+        ref1 = F.batch_norm(F.conv2d(x, w1, None, 2, 0), bn1[2], bn1[3], bn1[0], bn1[1], False, 0.0, 1e-5)
+        wp3, b3 = E.prepack_conv(w3, bn3, planes, dev)
+        wp1, b1 = E.prepack_conv(w1, bn1, planes, dev)
+        xpf = E.pf_pack(x.to(dev), planes)
+        o3, o1 = E.pf_zeros(n, cout, h // 2, w // 2, planes, dev), E.pf_zeros(n, cout, h // 2, w // 2, planes, dev)
+        native.check(lib.wsi_conv3x3s2_ds_fused(xpf.data_ptr(), o3.data_ptr(), o1.data_ptr(), wp3.data_ptr(), b3.data_ptr(),
+                                                wp1.data_ptr(), b1.data_ptr(), n, h, w, cin, cout, planes,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'fused s2')
+        g3 = E.pf_unpack(o3, n, cout, h // 2, w // 2, planes).cpu()
+        g1 = E.pf_unpack(o1, n, cout, h // 2, w // 2, planes).cpu()
+        assert _rel_err(g3, ref3) <= tol and _rel_err(g1, ref1) <= tol
+        real = E.pf_pack(torch.full_like(g3, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
+        assert not bool((o3.view(torch.int16)[~real] != 0).any()) and not bool((o1.view(torch.int16)[~real] != 0).any())

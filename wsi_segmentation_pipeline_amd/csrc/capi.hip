@@ -6,6 +6,7 @@
 #include <string.h>
 
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);
+int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st);
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
 int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
 int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st);
@@ -144,7 +145,7 @@ int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_ou
 }
 
 // ------------------------------------------------------------------------------------ single ops
-static int g_stem_fused = 1, g_stem_rows = 16;       // fused stem+maxpool kernel; pooled rows per workgroup
+static int g_stem_fused = 1, g_stem_rows = 32;       // fused stem+maxpool kernel; pooled rows per workgroup
 
 int wsi_stem_set_mode(int fused, int rows_per_seg) {
     if (rows_per_seg <= 0) return WSI_EINVAL;
@@ -169,6 +170,8 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
     return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
 }
 
+static int g_s2_slab = 1;                             // stride-2 convs: phase-slab kernel (1) or per-tap gather kernel (0)
+
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
                        int cfg = -1) {
@@ -179,6 +182,8 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.gi = pf_geom(n, h_in, w_in, cin);
     a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
     a.stride = stride; a.ksize = ksize; a.relu = relu;
+    a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
+    if (ksize == 3 && stride == 2 && cout % 128 == 0 && cfg != 0 && g_s2_slab) return wsi_s2_dispatch(a, planes, (hipStream_t)stream);
     return wsi_conv_dispatch(a, planes, cfg, (hipStream_t)stream);
 }
 
@@ -193,6 +198,23 @@ int wsi_conv3x3_bn_act_cfg(const void* in_pf, void* out_pf, const void* resid_pf
                            void* stream) {
     return conv_common(in_pf, out_pf, resid_pf, wpk, bias, n, h_in, w_in, cin, cout, stride, 3, relu, planes, stream, cfg);
 }
+
+int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf, const void* wpk3, const float* bias3,
+                           const void* wpk1, const float* bias1, int n, int h_in, int w_in, int cin, int cout, int planes,
+                           void* stream) {
+    if (!in_pf || !out_conv_pf || !out_ds_pf || !wpk3 || !bias3 || !wpk1 || !bias1 || n <= 0 || h_in % 2 || w_in % 2)
+        return WSI_EINVAL;
+    if (in_pf == out_conv_pf || in_pf == out_ds_pf || out_conv_pf == out_ds_pf) return WSI_EINVAL;
+    ConvArgs a;
+    a.in = in_pf; a.out = out_conv_pf; a.resid = nullptr; a.wpk = wpk3; a.bias = bias3;
+    a.gi = pf_geom(n, h_in, w_in, cin);
+    a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
+    a.stride = 2; a.ksize = 3; a.relu = 1;
+    a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
+    return wsi_s2_dispatch(a, planes, (hipStream_t)stream);
+}
+
+int wsi_conv_set_mode(int s2_slab) { g_s2_slab = s2_slab ? 1 : 0; return WSI_OK; }
 
 int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,
                    int cin, int cout, int stride, int planes, void* stream) {
@@ -397,10 +419,18 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 mid = ws + p.buf[s][1];
                 void* ds = ws + p.buf[s][2];
                 out = ws + p.buf[s][0];
-                PROF_CONV(2, n, H, W, C / 2, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, 2 * H,
+                if (g_s2_slab) {
+                    const int pi_ = prof_open(st, 2, 2.0 * n * H * W * (double)C * (C / 2) * 10);
+                    rc = wsi_conv3x3s2_ds_fused(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1], wt->down_b[s - 1], n,
+                                                2 * H, 2 * W, C / 2, C, planes, st);
+                    prof_close(st, pi_);
+                    if (rc) return rc;
+                } else {
+                    PROF_CONV(2, n, H, W, C / 2, C, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[wi], wt->conv_b[wi], n, 2 * H,
                                                                      2 * W, C / 2, C, 2, 1, planes, st));
-                PROF_CONV(3, n, H, W, C / 2, C, 1, wsi_conv1x1_bn(x, ds, wt->down_w[s - 1], wt->down_b[s - 1], n, 2 * H, 2 * W,
+    PROF_CONV(3, n, H, W, C / 2, C, 1, wsi_conv1x1_bn(x, ds, wt->down_w[s - 1], wt->down_b[s - 1], n, 2 * H, 2 * W,
                                                                  C / 2, C, 2, planes, st));
+                }
                 resid = ds;
                 cur = 0;
                 last_off = p.buf[s][0];

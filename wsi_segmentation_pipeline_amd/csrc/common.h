@@ -68,6 +68,10 @@ struct ConvArgs {
     int stride;            // 1 or 2
     int ksize;             // 3 or 1
     int relu;
+    // fused 1x1 stride-2 downsample branch of the stride-2 kernel (all null when unused)
+    void* out2;            // PF activations shaped like out
+    const void* wpk2;      // 1x1 weights [ntile][line][1][f][lane][8]
+    const float* bias2;
 };
 
 static inline __device__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {

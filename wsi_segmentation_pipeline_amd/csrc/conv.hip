@@ -133,6 +133,13 @@ static __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_ba
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Buffer-addressed form: source = resource base + 32-bit per-lane byte offset + scalar offset (no
+// 64-bit address VALU).  Kept in a plain __device__ function: used directly inside a kernel
+// template, this builtin makes hipcc's host pass drop the kernel stub (ROCm 7.2).
+static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // Stride-1 3x3: the input pixels a tile of BM consecutive PF positions needs form ONE contiguous
 // range [q0-P-1, q0+BM+P+1): stage that slab once per 128-byte line by LDS-DMA (all pieces in
 // flight at once, swizzle applied on the source address), then all nine taps are LDS address
@@ -514,6 +521,189 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+// --------------------------------------------------------------------------------------------
+// Stride-2 3x3 conv (+ fused 1x1 stride-2 downsample) in slab form.
+// in(2y+kh-1, 2x+kw-1) = phase image I[py][px](y+dy, x+dx) with (py,dy) = (1,-1),(0,0),(1,0) for
+// kh = 0,1,2 (same for kw): each of the four input phase images, viewed in the OUTPUT's padded-flat
+// geometry, is accessed with stride 1, so one contiguous region per phase is staged per 128-byte
+// line (sizes BM, BM+1, BM+P, BM+P+1 pixels) and the nine taps are LDS address shifts.  The 1x1
+// stride-2 downsample conv reads exactly the centre tap's pixels: it runs as a 10th tap with its
+// own weights into a second accumulator set (FUSE), so the block's two stride-2 convs cost one
+// pass over the input.  Ten taps are an even count: a 2-slot weight ring stays phase-aligned
+// across lines.
+template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MT * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int KMAX = ((4 * BM + 2 * 34 + 2) * 8 + NTHREADS - 1) / NTHREADS;      // pieces per thread, P <= 34
+    constexpr int NT = FUSE ? 10 : 9;
+    constexpr int RING = FUSE ? 2 : 3;                        // weight ring slots; NT % RING == 0 keeps lines aligned
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    const int nb = blockIdx.x % nblocks;
+    const int mtile = blockIdx.x / nblocks;
+    const int P = a.go.P;
+    const int q0 = a.go.G + mtile * BM;
+    const int R01 = BM, R10 = 2 * BM + 1, R11 = 3 * BM + 1 + P;                      // region bases (pixels)
+    const int npix = 4 * BM + 2 * P + 2;
+    const int npieces = npix * 8;
+    const int ntile = nb * WN + wn;
+    const int NC = a.gi.C * PLANES / 64;
+    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(FUSE ? a.wpk2 : a.wpk) + (size_t)ntile * NC * 4096), 0, NC * 4096, 0x00020000);
+    const int wvoff = lane * 16;
+
+    // source pixel (input PF index, 0 = a zero guard pixel) of every 16-byte piece this thread stages
+    int srcpix[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int i = wave * 64 + k * NTHREADS + lane;
+        const int Pl = i >> 3;
+        int reg = 0, j = Pl;
+        if (Pl >= R11) { reg = 3; j = Pl - R11; }
+        else if (Pl >= R10) { reg = 2; j = Pl - R10; }
+        else if (Pl >= R01) { reg = 1; j = Pl - R01; }
+        const int py = reg >> 1, px = reg & 1;
+        const int v = q0 - (py ? P : 0) - px + j;                                    // virtual position in the output geometry
+        int src = 0;
+        int r = v - a.go.G;
+        if (Pl < npix && r >= 0 && r < a.go.NS) {
+            const int n = r / a.go.S;
+            r -= n * a.go.S;
+            const int y = r / P, x = r - y * P;
+            if (x != a.go.W && y != a.go.H) src = a.gi.G + n * a.gi.S + (2 * y + py) * a.gi.P + 2 * x + px;
+        }
+        const int sl = (i & 7) ^ ((Pl >> 1) & 7);                                    // swizzled 16-byte slot
+        srcpix[k] = (int)((unsigned)src * (unsigned)in_pixstride + (unsigned)sl * 16u);   // byte offset (< 4 GiB, host-checked)
+    }
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0xffffffff, 0x00020000);
+
+    f32x16 acc[MT], accd[FUSE ? MT : 1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accd[mt][r] = 0.f;
+    }
+    int xoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
+
+    auto wload = [&](bf16x8(&w)[4], int c, int t) {           // t in [0,9): 3x3 tap, t == 9: downsample weights
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const u32x4 v = (t < 9) ? __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + f * 1024, (c * 9 + t) * 4096, 0)
+                                    : __builtin_amdgcn_raw_buffer_load_b128(wrd, wvoff + f * 1024, c * 4096, 0);
+            w[f] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    auto xload = [&](bf16x8(&x)[4], int Pl) {
+        const int base = lds_xbase(Pl, h);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+    };
+    // LDS pixel offset of tap t for tile row 0: region base + back + dy*P + dx
+    auto tap_off = [&](int t, int Pc) {
+        if (t == 9) return 0;                                  // centre pixels: region 00
+        const int kh = t / 3, kw = t % 3;
+        const int py = kh != 1, px = kw != 1;
+        const int base = py ? (px ? 3 * BM + 1 + Pc : 2 * BM + 1) : (px ? BM : 0);
+        const int back = (py ? Pc : 0) + px;
+        return base + back + (kh == 0 ? -Pc : 0) + (kw == 0 ? -1 : 0);
+    };
+
+    bf16x8 wbuf[RING][4], xf[2][4];
+    wload(wbuf[0], 0, 0);
+    for (int c = 0; c < NC; ++c) {
+        int Pc = P;
+        asm volatile("" : "+s"(Pc));
+        if (c) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i0 = wave * 64 + k * NTHREADS;
+            if (i0 < npieces)
+                dma16_buf(irs, smem + (size_t)i0 * 16, srcpix[k], c * 128);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        xload(xf[0], xoff[0] + tap_off(0, Pc));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" ::: "memory");
+            if (t + 1 < NT) wload(wbuf[(t + 1) % RING], c, t + 1);
+            else if (c + 1 < NC) wload(wbuf[0], c + 1, 0);
+            const int toff = tap_off(t, Pc);
+            const int toff_next = t + 1 < NT ? tap_off(t + 1, Pc) : 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int k = t * MT + mt;
+                if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
+                else if (t + 1 < NT) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                const bf16x8(&w)[4] = wbuf[t % RING];
+                const bf16x8(&x)[4] = xf[k & 1];
+                f32x16& d = (FUSE && t == 9) ? accd[FUSE ? mt : 0] : acc[mt];
+                if constexpr (PLANES == 2) {
+                    d = mfma_bf16(w[2], x[0], d);
+                    d = mfma_bf16(w[3], x[1], d);
+                    d = mfma_bf16(w[0], x[2], d);
+                    d = mfma_bf16(w[1], x[3], d);
+                    d = mfma_bf16(w[0], x[0], d);
+                    d = mfma_bf16(w[1], x[1], d);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
+                }
+            }
+        }
+    }
+    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+    if constexpr (FUSE) {
+        ConvArgs a2 = a;
+        a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
+        conv_epilogue<MT, PLANES>(a2, accd, q0 + wm * MT * 32, ntile, lane);
+    }
+}
+
+template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE>
+static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
+    if (a.go.C % (WN * 32) || a.go.P > 34) return WSI_EINVAL;
+    if ((unsigned long long)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * a.gi.C * PLANES * 2 >= 0xffffffffull) return WSI_EINVAL;
+    const int mtiles = (a.go.NS + BM - 1) / BM;
+    const int nblocks = a.go.C / (WN * 32);
+    const int npieces = (4 * BM + 2 * a.go.P + 2) * 8;
+    const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    if (lds > 160 * 1024) return WSI_EINVAL;
+    auto k = conv3x3s2_slab_kernel<MT, WM, WN, PLANES, MINW, FUSE>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return WSI_EINVAL;
+    }
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+// stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
+int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
+    if (a.gi.C % 64 || a.go.C % 128 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    if (a.go.H * 2 != a.gi.H || a.go.W * 2 != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
+    const bool fuse = a.out2 != nullptr;
+    if (fuse && (!a.wpk2 || !a.bias2)) return WSI_EINVAL;
+    if (planes == 2) return fuse ? launch_s2slab<4, 1, 4, 2, 2, true>(a, st) : launch_s2slab<4, 1, 4, 2, 2, false>(a, st);
+    return fuse ? launch_s2slab<4, 1, 4, 1, 2, true>(a, st) : launch_s2slab<4, 1, 4, 1, 2, false>(a, st);
 }
 
 template <int MT, int WM, int WN, int PLANES, int MINW>

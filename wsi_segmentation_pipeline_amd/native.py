@@ -43,6 +43,8 @@ SIGNATURES = {
     'wsi_stem_set_mode': (_i, [_i, _i]),
     'wsi_conv3x3_bn_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_conv3x3_bn_act_cfg': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'wsi_conv3x3s2_ds_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'wsi_conv_set_mode': (_i, [_i]),
     'wsi_conv1x1_bn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_avgpool_fc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     'wsi_linear': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
