@@ -18,19 +18,16 @@
 // Fused epilogue: bias (+ residual) (+ ReLU), split to bf16 planes, store.  acc[mt] covers
 // pixels q_base + mt*32 + (lane&31) and channels ntile*32 + 8g + 4h + i.
 template <int MT, int PLANES>
-static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT], int q_base, int ntile,
-                                                     int lane) {
-    const int l31 = lane & 31, h = lane >> 5;
+static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
+                                                       const bool (&valid)[MT], int ntile, int lane) {
+    const int h = lane >> 5;
     const size_t pixstride = (size_t)a.go.C * PLANES * 2;
     const size_t chan_off = (size_t)ntile * (64 * PLANES) + (size_t)(4 * h) * 2;
-    bool valid[MT];
     size_t poff[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int q = q_base + mt * 32 + l31;
-        valid[mt] = pf_is_pixel(a.go, q);
-        poff[mt] = (size_t)(valid[mt] ? q : a.go.G) * pixstride + chan_off;     // pad rows read a real pixel, store nothing
-    }
+    for (int mt = 0; mt < MT; ++mt)
+        poff[mt] = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + chan_off;   // invalid rows read a real pixel, store nothing
+
     // phase 1: every residual load of the tile in flight at once (branch-free)
     bf16x4 rh[MT][4], rl[MT][4];
     if (a.resid) {
@@ -91,6 +88,20 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             }
         }
     }
+}
+
+// contiguous-position form: tile rows are PF positions q_base + mt*32 + (lane&31), pads filtered here
+template <int MT, int PLANES>
+static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT], int q_base, int ntile,
+                                                     int lane) {
+    int qs[MT];
+    bool valid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        qs[mt] = q_base + mt * 32 + (lane & 31);
+        valid[mt] = pf_is_pixel(a.go, qs[mt]);
+    }
+    conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
 }
 
 // One 128-byte line of K for MT pixel tiles: 4 fragments per operand; the pixel fragments of tile
@@ -415,7 +426,11 @@ static int launch_slab2(const ConvArgs& a, hipStream_t st) {
 //   * a compiler scheduling fence per tap keeps hipcc from hoisting all nine taps' loads.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <int MT, int WM, int WN, int PLANES, int MINW>
+// DENSE: the tile enumerates REAL pixels only (n, y, x raster order) instead of consecutive PF
+// positions, so no MFMA work is spent on pad positions ((H+1)(W+1)/HW = 27 % at 8x8 maps); the
+// slab is still the contiguous range from the first to the last pixel's neighbourhood and each
+// lane simply carries its own slab offset.
+template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
@@ -429,12 +444,41 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const int nb = blockIdx.x % nblocks;                      // b % 8 picks the XCD: one channel block per XCD for nblocks | 8
     const int mtile = blockIdx.x / nblocks;
     const int P = a.gi.P;
-    const int q0 = a.gi.G + mtile * BM;
-    const int npieces = (BM + 2 * P + 2) * 8;
     const int ntile = nb * WN + wn;
     const int NC = (a.relu & 128) ? 0 : a.gi.C * PLANES / 64;  // ablation: no main loop, epilogue only
     const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
-    const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
+    int xoff[MT], qs[MT];                                     // slab-local pixel / PF position of each tile row
+    bool valid[MT];
+    int slab0, npieces;
+    if constexpr (DENSE) {
+        const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
+        auto pos = [&](int i) {
+            const int n = i / HW, rem = i - n * HW;
+            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
+            return a.gi.G + n * a.gi.S + y * P + x;
+        };
+        const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
+        slab0 = pos(i0) - P - 1;
+        npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            valid[mt] = i < R;
+            qs[mt] = pos(valid[mt] ? i : i1);
+            xoff[mt] = qs[mt] - slab0 - (P + 1);             // tap (0,0) adds toff relative to q - P - 1
+        }
+    } else {
+        const int q0 = a.gi.G + mtile * BM;
+        slab0 = q0 - P - 1;
+        npieces = (BM + 2 * P + 2) * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            xoff[mt] = wm * MT * 32 + mt * 32 + l31;
+            qs[mt] = q0 + xoff[mt];
+            valid[mt] = pf_is_pixel(a.go, qs[mt]);
+        }
+    }
+    const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
     const int wvoff = lane * 16;
@@ -444,10 +488,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-    int xoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
-
     auto wload = [&](bf16x8(&w)[4], int soff) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -502,19 +542,27 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             }
         }
     }
-    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+    conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
 }
 
-template <int MT, int WM, int WN, int PLANES, int MINW>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE>
 static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
     if (a.go.C % (WN * 32)) return WSI_EINVAL;
-    const int mtiles = (a.gi.NS + BM - 1) / BM;
     const int nblocks = a.go.C / (WN * 32);
-    const int npieces = (BM + 2 * a.gi.P + 2) * 8;
-    size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    int mtiles, maxpix;
+    if (DENSE) {
+        const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+        mtiles = (int)((R + BM - 1) / BM);
+        // BM real pixels span at most BM + one pad per started row + one pad row per image crossing
+        maxpix = BM + (BM + a.gi.W - 1) / a.gi.W + 1 + ((BM + a.gi.H * a.gi.W - 1) / (a.gi.H * a.gi.W) + 1) * a.gi.P + 2 * a.gi.P + 2;
+    } else {
+        mtiles = (a.gi.NS + BM - 1) / BM;
+        maxpix = BM + 2 * a.gi.P + 2;
+    }
+    const size_t lds = (size_t)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW>;
+    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
@@ -760,19 +808,18 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
 
 // software-pipelined variants: cfg 20 + index
 #define SLAB3_CFGS(X) \
-    X(20, 4, 1, 4, 2) \
-    X(21, 4, 2, 2, 2) \
-    X(22, 4, 1, 4, 3) \
-    X(23, 4, 2, 2, 3) \
-    X(24, 8, 1, 4, 2) \
-    X(25, 2, 2, 4, 3) \
-    X(26, 4, 1, 2, 3) \
-    X(27, 8, 2, 2, 2)
+    X(20, 4, 1, 4, 2, false) \
+    X(21, 4, 2, 2, 2, false) \
+    X(25, 2, 2, 4, 3, false) \
+    X(26, 4, 1, 2, 3, false) \
+    X(30, 4, 1, 4, 2, true) \
+    X(31, 4, 2, 2, 2, true) \
+    X(32, 2, 2, 4, 3, true)
 
 int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     switch (cfg) {
-#define X(id, MT, WM, WN, MINW) \
-    case id: return planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW>(a, st) : launch_slab3<MT, WM, WN, 1, MINW>(a, st);
+#define X(id, MT, WM, WN, MINW, DENSE) \
+    case id: return planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
         SLAB3_CFGS(X)
 #undef X
 #define X(id, MT, WM, WN, MINW) \
@@ -788,7 +835,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st
 }
 
 // default config per layer shape (tuned on MI355X, tools/tune_conv.py)
-static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 20 : 21; }   // r01 tune: profiles/r01_tune_conv*.log
+static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 30 : 31; }   // r01 tune: profiles/r01_tune_conv*.log
 
 // Host dispatch.  cfg < 0 selects the tuned default.
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
