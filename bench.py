@@ -46,7 +46,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--mode', choices=('parity', 'speed'), default='parity',
                     help='parity: bf16x2 split, 3 MFMA passes (meets 1e-3); speed: single-pass bf16')
-    ap.add_argument('--batch', type=int, default=500)
+    ap.add_argument('--batch', type=int, default=1000)
     ap.add_argument('--tiles', type=int, default=TILES_PER_GPU, help='tiles per GPU per step')
     ap.add_argument('--chunks', type=str, default='', help='stem_chunk,layer1_chunk sub-batch sizes (default: library default)')
     ap.add_argument('--stem', type=str, default='', help='fused,rows_per_seg for the stem kernel (A/B)')
