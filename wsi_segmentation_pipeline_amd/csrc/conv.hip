@@ -814,7 +814,11 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(26, 4, 1, 2, 3, false) \
     X(30, 4, 1, 4, 2, true) \
     X(31, 4, 2, 2, 2, true) \
-    X(32, 2, 2, 4, 3, true)
+    X(32, 2, 2, 4, 3, true) \
+    X(33, 4, 4, 2, 2, true) \
+    X(34, 8, 1, 4, 1, true) \
+    X(35, 8, 2, 2, 1, true) \
+    X(36, 4, 2, 4, 2, true)
 
 int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     switch (cfg) {

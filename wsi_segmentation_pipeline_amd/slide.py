@@ -124,10 +124,15 @@ def gather_tile_logits(local_logits, total, rank, world):
         return local_logits
     c = local_logits.shape[1]
     chunk = (total + world - 1) // world
-    buf = torch.zeros((chunk, c), dtype=local_logits.dtype, device=local_logits.device)
+    dev = local_logits.device
+    # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or ranks sharing one GPU) goes via host memory
+    via_host = dist.get_backend() != 'nccl' and local_logits.is_cuda
+    buf = torch.zeros((chunk, c), dtype=local_logits.dtype, device='cpu' if via_host else dev)
     buf[:local_logits.shape[0]] = local_logits
-    out = torch.empty((world * chunk, c), dtype=local_logits.dtype, device=local_logits.device)
+    out = torch.empty((world * chunk, c), dtype=local_logits.dtype, device=buf.device)
     dist.all_gather_into_tensor(out, buf)
+    if via_host:
+        out = out.to(dev)
     parts = []
     for r in range(world):
         lo, hi = shard_range(total, r, world)
