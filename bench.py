@@ -143,9 +143,17 @@ def main():
                                   'tflops': tfl / (tms * 1e-3) / 1e12, 'share_of_step': tms * 1e-3 / dt}
         if 'conv3x3_s1' in per_kind:
             ach = per_kind['conv3x3_s1']['tflops']
-            roofline = {'kernel': 'conv3x3s1_slab_kernel (12 launches per batch: layer1-4 stride-1 3x3 convs)',
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+            if os.path.exists(tpath) and planes == 2:
+                # HBM bytes per launch from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE,
+                # collected at batch 1000); scaled to this run's batch
+                tj = json.load(open(tpath))
+                traffic = round(tj['conv3x3_s1_hbm_bytes_per_launch'] * args.batch / 1000.0)
+            roofline = {'kernel': 'conv3x3s1_slab3_kernel (13 launches per batch: the stride-1 3x3 convs of layer1-4)',
                         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                        'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                        'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_traffic.json)',
                         'avg_launch_ms': round(per_kind['conv3x3_s1']['avg_ms'], 4),
                         'mfma_passes': 3 if planes == 2 else 1}
     if world > 1:
