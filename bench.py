@@ -168,17 +168,23 @@ def main():
         nsample = 32
         xy = tiles[:nsample]
         u8 = torch.stack([level0[y:y + TILE, x:x + TILE] for x, y in xy]).permute(0, 3, 1, 2).contiguous().cpu().numpy()
-        cores = torch.get_num_threads()
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        best = None
         with torch.no_grad():
-            ref = R.tile_logits(sd, cls, u8)                                 # warm-up (also a sanity check)
-            ts = []
-            for _ in range(3):
-                c0 = time.perf_counter()
-                R.tile_logits(sd, cls, u8)
-                ts.append(time.perf_counter() - c0)
+            for cores in sorted({min(16, avail), avail}):        # the GPU box's CPU share is 16 cores per GPU
+                torch.set_num_threads(cores)
+                ref = R.tile_logits(sd, cls, u8)                               # warm-up (also the sanity reference)
+                ts = []
+                for _ in range(3):
+                    c0 = time.perf_counter()
+                    R.tile_logits(sd, cls, u8)
+                    ts.append(time.perf_counter() - c0)
+                if best is None or float(np.median(ts)) < best[0]:
+                    best = (float(np.median(ts)), cores)
+        ts, cores = [best[0]], best[1]
         got = out['logits'][:nsample].cpu()
         cpu_baseline = {'value': round(nsample / float(np.median(ts)), 2), 'unit': 'patches/s', 'cores': cores,
-                        'kind': 'port', 'sample': 'first %d tiles of the same slide, fp32 torch CPU oracle, median of 3' % nsample,
+                        'kind': 'port', 'sample': 'first %d tiles of the same slide, fp32 torch CPU oracle, median of 3, best of 16 / all host threads' % nsample,
                         'max_abs_logit_diff_vs_gpu': float((got - ref).abs().max())}
 
     if rank == 0:
