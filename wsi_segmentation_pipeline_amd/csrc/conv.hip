@@ -294,130 +294,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 
 // --------------------------------------------------------------------------------------------
 // --------------------------------------------------------------------------------------------
-// Slab kernel, pipelined form: two slab buffers; the DMA of line c+1 is issued during tap 0 of line
-// c and has two taps of MFMA work to land; ONE raw barrier per line.  Weight fragments are loaded
-// by inline asm (invisible to hipcc's waitcnt pass, so they do not drain the DMA) and retired by
-// hand-counted s_waitcnt vmcnt: VMEM issue order per line is  W(1), DMA(c+1) x ND, W(2), W(3)...
-//   tap 1 needs W(1): everything younger is the ND DMA pieces      -> vmcnt(ND)
-//   every other tap needs the newest load                           -> vmcnt(0)
-static __device__ __forceinline__ void wload4(bf16x8 (&w)[4], const bf16x8* p) {
-    asm volatile(
-        "global_load_dwordx4 %0, %4, off\n\t"
-        "global_load_dwordx4 %1, %4, off offset:1024\n\t"
-        "global_load_dwordx4 %2, %4, off offset:2048\n\t"
-        "global_load_dwordx4 %3, %4, off offset:3072"
-        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-        : "v"(p)
-        : "memory");
-}
-#define WWAIT(N, w) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory")
-static __device__ __forceinline__ void wwait_n(int nd, bf16x8 (&w)[4]) {
-    switch (nd) {                       // wave-uniform
-        case 0: WWAIT(0, w); break;
-        case 1: WWAIT(1, w); break;
-        case 2: WWAIT(2, w); break;
-        case 3: WWAIT(3, w); break;
-        case 4: WWAIT(4, w); break;
-        case 5: WWAIT(5, w); break;
-        case 6: WWAIT(6, w); break;
-        case 7: WWAIT(7, w); break;
-        case 8: WWAIT(8, w); break;
-        case 9: WWAIT(9, w); break;
-        case 10: WWAIT(10, w); break;
-        case 11: WWAIT(11, w); break;
-        case 12: WWAIT(12, w); break;
-        default: WWAIT(0, w); break;
-    }
-}
-
-template <int MT, int WM, int WN, int PLANES, int MINW>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab2_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = WM * MT * 32;
-    constexpr int NTHREADS = WM * WN * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nblocks = a.go.C / (WN * 32);
-    const int nb = blockIdx.x % nblocks;
-    const int mtile = blockIdx.x / nblocks;
-    const int P = a.gi.P;
-    const int q0 = a.gi.G + mtile * BM;
-    const int npieces = (BM + 2 * P + 2) * 8;
-    const int nd = __builtin_amdgcn_readfirstlane((npieces - wave * 64 + NTHREADS - 1) / NTHREADS);   // DMA instrs per wave per line
-    const int bufbytes = (npieces + NTHREADS - 1) / NTHREADS * NTHREADS * 16;
-    const int ntile = nb * WN + wn;
-    const int NC = a.gi.C * PLANES / 64;
-    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
-    const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
-    const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * 9 * 4 * 64 + lane;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-    int xoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
-
-    auto stage = [&](int c, char* buf) {
-        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
-            const int i = i0 + lane;
-            const int Pl = i >> 3, sp = i & 7;
-            const int s = sp ^ ((Pl >> 1) & 7);
-            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16, buf + (size_t)i0 * 16);
-        }
-    };
-
-    bf16x8 wcur[4], wnxt[4];
-    wload4(wnxt, wbase);                                      // W(0,0)
-    stage(0, smem);
-    for (int c = 0; c < NC; ++c) {
-        const char* buf = smem + (c & 1) * bufbytes;
-        // line c's slab: own DMA pieces retired (vmcnt(0) also retires W(c,0)), then everyone's
-        WWAIT(0, wnxt);
-        __builtin_amdgcn_s_barrier();
-        const bf16x8* wp = wbase + (size_t)c * 9 * 4 * 64;
-#pragma unroll 1
-        for (int t = 0; t < 9; ++t) {
-            if (t == 1) wwait_n(c + 1 < NC ? nd : 0, wnxt);
-            else if (t > 1) WWAIT(0, wnxt);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) wcur[f] = wnxt[f];
-            if (t < 8) wload4(wnxt, wp + (size_t)(t + 1) * 4 * 64);
-            else if (c + 1 < NC) wload4(wnxt, wp + (size_t)9 * 4 * 64);
-            if (t == 0 && c + 1 < NC) stage(c + 1, smem + ((c + 1) & 1) * bufbytes);
-            const int toff = (t / 3 - 1) * P + (t % 3 - 1) + P + 1;
-            int xbase[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(xoff[mt] + toff, h);
-            mfma_line<MT, PLANES>(acc, wcur, buf, xbase);
-        }
-    }
-    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
-}
-
-template <int MT, int WM, int WN, int PLANES, int MINW>
-static int launch_slab2(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
-    if (a.go.C % (WN * 32)) return WSI_EINVAL;
-    const int mtiles = (a.gi.NS + BM - 1) / BM;
-    const int nblocks = a.go.C / (WN * 32);
-    const int npieces = (BM + 2 * a.gi.P + 2) * 8;
-    if ((npieces + NTHREADS - 1) / NTHREADS > 12) return WSI_EINVAL;     // wwait_n table
-    const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16 * 2;
-    if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_slab2_kernel<MT, WM, WN, PLANES, MINW>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return WSI_EINVAL;
-    }
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
-    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
-}
-
-// --------------------------------------------------------------------------------------------
 // Slab kernel, software-pipelined form.  Per 128-byte line the nine taps are straight-line code:
 //   * weight fragments come through buffer loads (scalar offset per tap, no address VALU) into a
 //     3-slot register ring indexed statically (tap % 3): no copies, prefetch distance one tap;
@@ -797,15 +673,6 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(8, 4, 4, 2, 2)  \
     X(9, 4, 1, 2, 2)
 
-// pipelined (double-buffered) variants: cfg 10 + index
-#define SLAB2_CFGS(X) \
-    X(10, 4, 1, 4, 2) \
-    X(11, 4, 2, 2, 2) \
-    X(12, 8, 1, 4, 2) \
-    X(13, 4, 1, 2, 2) \
-    X(14, 8, 1, 2, 2) \
-    X(15, 2, 2, 4, 2)
-
 // software-pipelined variants: cfg 20 + index
 #define SLAB3_CFGS(X) \
     X(20, 4, 1, 4, 2, false) \
@@ -825,10 +692,6 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st
 #define X(id, MT, WM, WN, MINW, DENSE) \
     case id: return planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
         SLAB3_CFGS(X)
-#undef X
-#define X(id, MT, WM, WN, MINW) \
-    case id: return planes == 2 ? launch_slab2<MT, WM, WN, 2, MINW>(a, st) : launch_slab2<MT, WM, WN, 1, MINW>(a, st);
-        SLAB2_CFGS(X)
 #undef X
 #define X(id, MT, WM, WN, MINW) \
     case id: return planes == 2 ? launch_slab<MT, WM, WN, 2, MINW>(a, st) : launch_slab<MT, WM, WN, 1, MINW>(a, st);
