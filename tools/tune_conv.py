@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsi_segmentation_pipeline_amd import engine as E, native  # noqa: E402
 
 SHAPES = [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]      # (C, H, W) for 256x256 patches
-NCFG = 37
+NCFG = 39
 
 
 def main():
@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--cfgs', type=str, default='')
     ap.add_argument('--ablate', type=str, default='1', help='comma list of relu/ablation bit masks')
     ap.add_argument('--noresid', action='store_true')
+    ap.add_argument('--zero', action='store_true', help='all-zero activations (clock / power test)')
     ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
     args = ap.parse_args()
     lib = native.load()
@@ -36,6 +37,8 @@ def main():
         h, w = h // args.scale, w // args.scale
         n = args.n
         x = torch.randn(n, c, h, w, generator=g).abs_()
+        if args.zero:
+            x.zero_()
         wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
         wpk, bias = E.prepack_conv(wt, None, args.planes, dev)
         xpf = E.pf_pack(x.to(dev), args.planes)

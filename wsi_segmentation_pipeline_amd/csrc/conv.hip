@@ -395,6 +395,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         for (int t = 0; t < 9; ++t) {
             asm volatile("" ::: "memory");                    // scheduling fence: keep later taps' loads below
             if (t < 8) wload(wbuf[(t + 1) % 3], sline + (t + 1) * 4096);
+            asm volatile("" ::: "memory");                    // ...and keep THIS prefetch above the tap's MFMAs: without
+                                                              // it hipcc sinks the loads to the end of the tap (distance 0)
             const int toff = (t / 3) * Pc + (t % 3);
             const int toff_next = ((t + 1) / 3) * Pc + ((t + 1) % 3);
 #pragma unroll
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
             asm volatile("" ::: "memory");
             if (t + 1 < NT) wload(wbuf[(t + 1) % RING], c, t + 1);
             else if (c + 1 < NC) wload(wbuf[0], c + 1, 0);
+            asm volatile("" ::: "memory");                    // pin the prefetch above this tap's MFMAs
             const int toff = tap_off(t, Pc);
             const int toff_next = t + 1 < NT ? tap_off(t + 1, Pc) : 0;
 #pragma unroll
@@ -682,13 +685,13 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(30, 4, 1, 4, 2, true) \
     X(31, 4, 2, 2, 2, true) \
     X(32, 2, 2, 4, 3, true) \
-    X(33, 4, 4, 2, 2, true) \
-    X(34, 8, 1, 4, 1, true) \
-    X(35, 8, 2, 2, 1, true) \
-    X(36, 4, 2, 4, 2, true)
+    X(36, 4, 2, 4, 2, true) \
+    X(37, 4, 1, 4, 3, true) \
+    X(38, 4, 2, 2, 3, true)
 
 int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     switch (cfg) {
+
 #define X(id, MT, WM, WN, MINW, DENSE) \
     case id: return planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
         SLAB3_CFGS(X)
