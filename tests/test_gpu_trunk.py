@@ -108,3 +108,43 @@ def test_golden_tile_logits_256(dev, sd, golden_dir):
     ferr = float(np.abs(fmap.cpu().numpy()[:, ::16] - g['fmap_sub']).max())
     print('tile logits max abs err %.2e, feature map err %.2e' % (err, ferr))
     assert err <= LOGIT_TOL and ferr <= 1e-3
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 32), (1, 64, 64), (3, 96, 160), (2, 160, 64), (1, 512, 512), (5, 256, 256)])
+def test_edge_patch_shapes_vs_oracle(dev, sd, shape):
+    """Smallest / non-square / large patches and ragged batch sizes through every stage (the 1x1 maps of
+    32x32 patches, the gather fallback of 512x512 ones) against the CPU oracle."""
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    n, h, w = shape
+    u8 = W.make_u8_patches(100 + h + w, (n, 3, h, w))
+    x = R.normalize_u8(u8)
+    eng = TrunkEngine(sd, dev, planes=2, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=4)
+    feat, logits, fmap = eng.forward_f32(x.to(dev), feat=True, logits=True, fmap=True)
+    with torch.no_grad():
+        rf = R.trunk(sd, x)
+        rfeat = torch.flatten(torch.nn.functional.adaptive_avg_pool2d(rf, 1), 1)
+        rlog = torch.nn.functional.linear(rfeat, sd['fc0.weight'], sd['fc0.bias'])
+    assert fmap.shape == rf.shape
+    assert float((fmap.cpu() - rf).abs().max() / rf.abs().max()) <= 2e-4
+    assert float((feat.cpu() - rfeat).abs().max()) <= 1e-3
+    assert float((logits.cpu() - rlog).abs().max()) <= LOGIT_TOL
+
+
+def test_unfused_reference_kernels_agree(dev, sd):
+    """The A/B forms kept in the library (two-kernel stem, gather stride-2 + separate downsample) give
+    the same logits as the fused defaults."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    u8 = W.make_u8_patches(77, (6, 3, 128, 128))
+    x = R.normalize_u8(u8).to(dev)
+    eng = TrunkEngine(sd, dev, planes=2, head=(sd['fc0.weight'], sd['fc0.bias']))
+    base = eng.forward_f32(x, logits=True)[1].clone()
+    try:
+        native.check(lib.wsi_stem_set_mode(0, 32), 'stem mode')
+        native.check(lib.wsi_conv_set_mode(0), 'conv mode')
+        alt = eng.forward_f32(x, logits=True)[1].clone()
+    finally:
+        lib.wsi_stem_set_mode(1, 32)
+        lib.wsi_conv_set_mode(1)
+    assert float((alt - base).abs().max()) <= 1e-4

@@ -183,7 +183,10 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
     a.stride = stride; a.ksize = ksize; a.relu = relu;
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
-    if (ksize == 3 && stride == 2 && cout % 128 == 0 && cfg != 0 && g_s2_slab) return wsi_s2_dispatch(a, planes, (hipStream_t)stream);
+    if (ksize == 3 && stride == 2 && cout % 128 == 0 && cfg != 0 && g_s2_slab) {
+        const int rc = wsi_s2_dispatch(a, planes, (hipStream_t)stream);
+        if (rc != WSI_EINVAL) return rc;               // EINVAL: shape outside the slab kernel's range -> gather kernel
+    }
     return wsi_conv_dispatch(a, planes, cfg, (hipStream_t)stream);
 }
 
@@ -211,7 +214,12 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
     a.stride = 2; a.ksize = 3; a.relu = 1;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
-    return wsi_s2_dispatch(a, planes, (hipStream_t)stream);
+    int rc = wsi_s2_dispatch(a, planes, (hipStream_t)stream);
+    if (rc == WSI_EINVAL) {                             // e.g. maps wider than 33: two per-tap gather launches
+        rc = conv_common(in_pf, out_conv_pf, nullptr, wpk3, bias3, n, h_in, w_in, cin, cout, 2, 3, 1, planes, stream, 0);
+        if (!rc) rc = conv_common(in_pf, out_ds_pf, nullptr, wpk1, bias1, n, h_in, w_in, cin, cout, 2, 1, 0, planes, stream, 0);
+    }
+    return rc;
 }
 
 int wsi_conv_set_mode(int s2_slab) { g_s2_slab = s2_slab ? 1 : 0; return WSI_OK; }
