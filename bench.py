@@ -93,7 +93,10 @@ def main():
     total_tiles = args.tiles * world
     iw, ih = slide_geometry(total_tiles)
     g = torch.Generator(device=dev).manual_seed(3)
-    level0 = torch.randint(0, 256, (ih, iw, 3), dtype=torch.uint8, device=dev, generator=g)   # same on every rank
+    level0 = torch.empty((ih, iw, 3), dtype=torch.uint8, device=dev)             # same content on every rank
+    band = max(1, (1 << 30) // (iw * 3))                                         # <= 1 Gi elements per RNG call
+    for y0 in range(0, ih, band):
+        level0[y0:y0 + band] = torch.randint(0, 256, (min(band, ih - y0), iw, 3), dtype=torch.uint8, device=dev, generator=g)
     tiles = S.tile_grid(iw, ih, TILE, TILE, TILE, TILE)[:total_tiles]
     assert len(tiles) == total_tiles, (len(tiles), total_tiles)
     m = 1.0 / 16.0                                       # downsample[0] / downsample[2]
