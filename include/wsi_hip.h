@@ -146,6 +146,9 @@ int wsi_tile_gather(const uint8_t* slide, long long slide_pitch_bytes, int slide
                     const float* lut, float* out_nchw, int n, int ph, int pw, void* stream);
 int wsi_stitch_add(const float* tile_logits, const int* map_xy, int t, int c, int dy, int dx, double* pred, int map_h,
                    int map_w, void* stream);
+/* dense form (utils/eval.py:58-60, predict_wsis): tile_pred [t][c][ph][pw] fp32 added at map_xy */
+int wsi_stitch_add_dense(const float* tile_pred, const int* map_xy, int t, int c, int ph, int pw, double* pred, int map_h,
+                         int map_w, void* stream);
 int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream);
 

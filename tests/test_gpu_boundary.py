@@ -172,3 +172,42 @@ def test_region_bags_and_paint_match_oracle(dev, sd_full):
     assert np.abs(ens.cpu().numpy() - ens_ref.numpy()).max() <= LOGIT_TOL
     got_mask = val.predict_regions(model, it, metadata, label_shape)
     assert np.array_equal(got_mask, ref_mask)
+
+
+def test_predict_wsis_dense_accumulate_matches_oracle(dev, tmp_path):
+    """predict_wsis with a caller-supplied dense GPU module: device accumulate == the oracle's float64
+    slice-add (bit-exact: the per-pixel function below is exact in fp32 on CPU and GPU)."""
+    import myargs
+    import utils.dataset as ds
+    import utils.eval as val
+    from wsi_segmentation_pipeline_amd.slide import ArraySlide
+    a = myargs.args
+    a.scan_level, a.scan_resize, a.num_classes, a.class_probs = 0, 1, 4, [0., 0., 0., 0.]
+    a.tile_w = a.tile_h = 64
+    a.tile_stride_w = a.tile_stride_h = 40                       # overlapping tiles
+    a.val_save_pth, a.wsi_mask_pth = str(tmp_path / 'out'), str(tmp_path / 'nomask')
+    l0 = _he_slide(9, 400, 520)
+    slide = ArraySlide([l0, l0[::4, ::4], l0[::16, ::16]], [1.0, 4.0, 16.0])
+    slide.name = 'dense.svs'
+
+    class Dense(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.scale = torch.nn.Parameter(torch.tensor([1.0, -2.0, 0.5, 4.0]))
+
+        def forward(self, x):                                     # (B,3,h,w) -> (B,4,h,w), exact arithmetic
+            return torch.stack([x[:, c % 3] * self.scale[c] for c in range(4)], 1)
+
+    model = Dense().cuda()
+    dataset = ds.Dataset_wsis({'dense.svs': slide}, {'ph': 64, 'pw': 64, 'sh': 40, 'sw': 40}, bs=7)
+    tiles = dataset.wsis['dense.svs']['iterator'].dataset.datalist
+    assert len(tiles) > 20
+    res = val.predict_wsis(model, dataset, 3)['dense.svs']
+    u8 = np.stack([WO.read_tile(l0, x, y, 64, 64) for x, y in tiles]).transpose(0, 3, 1, 2)
+    xn = R.normalize_u8(u8)
+    with torch.no_grad():
+        tile_pred = Dense()(xn).numpy()
+    ref = WO.stitch_wsis(tiles, tile_pred, 4, l0.shape[:2], 64, 64)
+    assert np.array_equal(res['pred'].cpu().numpy(), ref)
+    assert np.array_equal(res['classes'].cpu().numpy(), np.argmax(ref, 0).astype(np.uint8))
+    assert os.path.exists('%s/3/dense.svs_40.png' % a.val_save_pth)

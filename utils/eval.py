@@ -8,7 +8,9 @@ the float64 map by wsi_stitch_add and the softmax/threshold/argmax/heat-map is o
 finished u8 images are copied back to be written as PNG.  There is no CPU fallback.
 
 Scope: the 'cls' path composes with the first-party backbone and is implemented
-here; mode='seg' needs the third-party smp U-Net decoder (absent, parity-unpinned) and raises."""
+end to end; predict_tumorbed(mode='seg') needs the third-party smp U-Net decoder (absent, parity-
+unpinned) and raises; predict_wsis runs any caller-supplied dense GPU module and does the
+accumulate / arg-max on the device."""
 import os
 
 import numpy as np
@@ -118,11 +120,54 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
     return results
 
 
-def predict_wsis(model, dataset, ep):
-    """Dense per-pixel map prediction (reference :22-152) needs a segmentation decoder
-    (third-party smp model in the reference); not part of the first-party 'cls' path."""
-    raise NotImplementedError('predict_wsis drives a dense segmentation model (smp.Unet in the reference), which is '
-                              'third-party and absent; the first-party path is predict_tumorbed(mode="cls")')
+def predict_wsis(model, dataset, ep, save=True):
+    """Dense per-pixel map prediction (reference utils/eval.py:22-152): `model(batch_image)` must return
+    (B, C, ph, pw) logits on the GPU (the reference drives a third-party smp model here; any GPU module
+    works).  The accumulate `pred[:, y:y+ph, x:x+pw] += pred_src[b]` (:58-60) runs on the device in
+    float64 at scan-level resolution (wsi_stitch_add_dense) - 51 GB for a 40k x 40k slide, which the
+    host-side reference cannot hold but HBM can - followed by the class arg-max (wsi_softmax_threshold_argmax).
+    Returns {key: {'pred': float64 (C,H,W) tensor, 'classes': u8 (H,W) tensor}} and writes
+    <val_save_pth>/<ep>/<key>_<stride>.png (class colours on the foreground mask).  The reference's
+    score printing and tumour-bed outline (cv2 / skimage / mahotas post-processing)
+    are not reproduced."""
+    out_dir = '{}/{}'.format(args.val_save_pth, ep)
+    if save:
+        os.makedirs(out_dir, exist_ok=True)
+    dev = _device_of(model)
+    was_training = model.training
+    model.eval()
+    results = {}
+    with torch.no_grad():
+        for key in list(dataset.wsis):
+            entry = dataset.wsis[key]
+            it = entry['iterator']
+            ds, scan = it.dataset, entry['scan']
+            iw, ih = scan.level_dimensions[args.scan_level]
+            pred = torch.zeros((args.num_classes, ih, iw), dtype=torch.float64, device=dev)
+            for batch_x, batch_y, batch_image in it:
+                pred_src = model(batch_image.to(dev))
+                if pred_src.dim() != 4 or pred_src.shape[1] != args.num_classes:
+                    raise ValueError('predict_wsis needs a dense model returning (B, %d, ph, pw)' % args.num_classes)
+                xy = torch.stack((batch_x, batch_y), 1).to(torch.int32)        # int(batch_x[bj]): truncation
+                E.stitch_add_dense(pred, pred_src, xy)
+            classes, _, _ = E.softmax_threshold_argmax(pred, [0.0] * args.num_classes, want_probs=False)
+            results[key] = {'pred': pred, 'classes': classes}
+            if save:
+                cls = classes.cpu().numpy()
+                mask = entry.get('mask')
+                rgb = np.zeros(cls.shape + (3,), np.uint8)
+                for cj in range(min(args.num_classes - 1, 3)):                  # class k>0 -> channel k-1, like pred_to_mask
+                    rgb[cls == cj + 1, cj] = 255
+                if mask is not None and tuple(mask.shape) != cls.shape:
+                    ys = (np.arange(cls.shape[0]) * mask.shape[0] // cls.shape[0]).clip(0, mask.shape[0] - 1)
+                    xs = (np.arange(cls.shape[1]) * mask.shape[1] // cls.shape[1]).clip(0, mask.shape[1] - 1)
+                    mask = np.asarray(mask)[ys][:, xs]
+                if mask is not None:
+                    rgb = rgb * (np.asarray(mask) > 0)[..., None].astype(np.uint8)
+                _save_png(rgb, '{}/{}_{}.png'.format(out_dir, key, args.tile_stride_w))
+    if was_training:
+        model.train()
+    return results
 
 
 def predict_regions(model, iterator, metadata, label_shape, class_probs=None):

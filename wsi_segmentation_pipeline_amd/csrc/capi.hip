@@ -20,6 +20,8 @@ int wsi_tile_gather_dispatch(const uint8_t* slide, long long pitch, int SH, int 
                              float* out, int N, int ph, int pw, hipStream_t st);
 int wsi_stitch_add_dispatch(const float* logits, const int* txy, int T, int C, int dy, int dx, double* pred, int MH, int MW,
                             hipStream_t st);
+int wsi_stitch_add_dense_dispatch(const float* tiles, const int* txy, int T, int C, int ph, int pw, double* pred, int MH,
+                                  int MW, hipStream_t st);
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
                          const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
 
@@ -263,6 +265,12 @@ int wsi_stitch_add(const float* tile_logits, const int* map_xy, int t, int c, in
                    int map_w, void* stream) {
     if (!tile_logits || !map_xy || !pred || map_h <= 0 || map_w <= 0) return WSI_EINVAL;
     return wsi_stitch_add_dispatch(tile_logits, map_xy, t, c, dy, dx, pred, map_h, map_w, (hipStream_t)stream);
+}
+
+int wsi_stitch_add_dense(const float* tile_pred, const int* map_xy, int t, int c, int ph, int pw, double* pred, int map_h,
+                         int map_w, void* stream) {
+    if (!tile_pred || !map_xy || !pred || map_h <= 0 || map_w <= 0) return WSI_EINVAL;
+    return wsi_stitch_add_dense_dispatch(tile_pred, map_xy, t, c, ph, pw, pred, map_h, map_w, (hipStream_t)stream);
 }
 
 int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,

@@ -45,6 +45,23 @@ __global__ __launch_bounds__(256) void stitch_add_kernel(const float* logits, co
     }
 }
 
+// Dense form of the same accumulate (reference utils/eval.py:58-60, predict_wsis): every tile carries a
+// (C, ph, pw) block.  One thread per (tile, pixel); numpy slice clipping at the map border.
+__global__ __launch_bounds__(256) void stitch_add_dense_kernel(const float* tiles, const int* txy, int T, int C, int ph, int pw,
+                                                               double* pred, int MH, int MW) {
+    const long long total = (long long)T * ph * pw;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int fx = (int)(i % pw);
+        long long p = i / pw;
+        const int fy = (int)(p % ph);
+        const int t = (int)(p / ph);
+        const int x = txy[2 * t] + fx, y = txy[2 * t + 1] + fy;
+        if (x < 0 || x >= MW || y < 0 || y >= MH) continue;
+        for (int c = 0; c < C; ++c)
+            atomicAdd(pred + ((size_t)c * MH + y) * MW + x, (double)tiles[(((size_t)t * C + c) * ph + fy) * pw + fx]);
+    }
+}
+
 #define WSI_MAX_CLASSES 16
 __global__ __launch_bounds__(256) void softmax_threshold_argmax_kernel(const double* pred, int C, long long HW,
                                                                        const double* thresh, double* probs,
@@ -91,6 +108,14 @@ int wsi_stitch_add_dispatch(const float* logits, const int* txy, int T, int C, i
                             hipStream_t st) {
     if (T <= 0 || C <= 0 || dy <= 0 || dx <= 0) return WSI_EINVAL;
     hipLaunchKernelGGL(stitch_add_kernel, dim3(grid_for((long long)T * dy * dx)), dim3(256), 0, st, logits, txy, T, C, dy, dx,
+                       pred, MH, MW);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_stitch_add_dense_dispatch(const float* tiles, const int* txy, int T, int C, int ph, int pw, double* pred, int MH,
+                                  int MW, hipStream_t st) {
+    if (T <= 0 || C <= 0 || ph <= 0 || pw <= 0) return WSI_EINVAL;
+    hipLaunchKernelGGL(stitch_add_dense_kernel, dim3(grid_for((long long)T * ph * pw)), dim3(256), 0, st, tiles, txy, T, C, ph, pw,
                        pred, MH, MW);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }

@@ -318,6 +318,20 @@ def stitch_add(pred, tile_logits, map_xy, dy, dx):
     return pred
 
 
+def stitch_add_dense(pred, tile_pred, map_xy):
+    """pred (C,MH,MW) float64 GPU += tile_pred (T,C,ph,pw) fp32 blocks at map_xy (T,2) int32 (clipped at the border)."""
+    lib = native.load()
+    _require_gpu(pred, 'prediction map')
+    if pred.dtype != torch.float64 or not pred.is_contiguous():
+        raise ValueError('pred must be a contiguous float64 tensor')
+    tile_pred = tile_pred.to(pred.device, torch.float32).contiguous()
+    map_xy = map_xy.to(pred.device, torch.int32).contiguous()
+    t, c, ph, pw = tile_pred.shape
+    native.check(lib.wsi_stitch_add_dense(_ptr(tile_pred), _ptr(map_xy), t, c, ph, pw, _ptr(pred), pred.shape[1], pred.shape[2],
+                                          _stream()), 'wsi_stitch_add_dense')
+    return pred
+
+
 def softmax_threshold_argmax(pred, class_probs, mask=None, heat_mode=None, want_probs=True):
     """pred (C,H,W) float64 GPU -> (classes u8 (H,W), probs f64 (C,H,W) or None, heat u8 (H,W) or None)."""
     lib = native.load()

@@ -59,6 +59,7 @@ SIGNATURES = {
     'wsi_prof_end': (_i, [_vp, _vp, _vp, _i]),
     'wsi_tile_gather': (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'wsi_stitch_add': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    'wsi_stitch_add_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_softmax_threshold_argmax': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
