@@ -50,24 +50,35 @@ def conv_scheme(x, w, stride, pad, main, cross):
     return out + F.conv2d(qx(xl), qw(wh), None, stride, pad) + F.conv2d(qx(xh), qw(wl), None, stride, pad)
 
 
-def forward(sd, x, main, cross):
+def store(x, cross, main):
+    """What the next layer / the residual sees when activations are stored as (hi, q(lo))."""
+    if cross in (None, 'exact16'):
+        return x
+    cast = (lambda t: t.half().float()) if main == 'fp16' else (lambda t: t.bfloat16().float())
+    grid = FP4 if cross == 'fp4' else FP6
+    xh = cast(x)
+    return xh + q_block(x - xh, 1, grid)
+
+
+def forward(sd, x, main, cross, stored=False):
     def bnfold(wk, bnk):
         s = sd[bnk + '.weight'].double() / torch.sqrt(sd[bnk + '.running_var'].double() + 1e-5)
         return (sd[wk].double() * s.view(-1, 1, 1, 1)).float(), (sd[bnk + '.bias'].double() - sd[bnk + '.running_mean'].double() * s).float()
     def cv(x, wk, bnk, stride, pad):
         w, b = bnfold(wk, bnk)
         return conv_scheme(x, w, stride, pad, main, cross) + b.view(1, -1, 1, 1)
+    sto = (lambda t: store(t, cross, main)) if stored else (lambda t: t)
     x = F.relu(cv(x, 'conv1.weight', 'bn1', 2, 3))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = sto(F.max_pool2d(x, 3, 2, 1))
     for li, st in ((1, 1), (2, 2), (3, 2), (4, 2)):
         for bi in range(2):
             p = 'layer%d.%d' % (li, bi)
             s = st if bi == 0 else 1
-            y = F.relu(cv(x, p + '.conv1.weight', p + '.bn1', s, 1))
+            y = sto(F.relu(cv(x, p + '.conv1.weight', p + '.bn1', s, 1)))
             y = cv(y, p + '.conv2.weight', p + '.bn2', 1, 1)
             if (p + '.downsample.0.weight') in sd:
-                x = cv(x, p + '.downsample.0.weight', p + '.downsample.1', s, 0)
-            x = F.relu(y + x)
+                x = sto(cv(x, p + '.downsample.0.weight', p + '.downsample.1', s, 0))
+            x = sto(F.relu(y + x))
     f = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
     return F.linear(f, sd['fc0.weight'], sd['fc0.bias'])
 
@@ -75,14 +86,18 @@ def forward(sd, x, main, cross):
 def main():
     torch.set_num_threads(8)
     sd = W.make_resnet18_state_dict(11, with_fc=False)
-    u8 = W.make_u8_patches(1, (4, 16, 3, 256, 256)).reshape(-1, 3, 256, 256)[:16]
+    u8 = W.make_u8_patches(1, (4, 16, 3, 256, 256)).reshape(-1, 3, 256, 256)[:32]
     x = R.normalize_u8(u8)
     with torch.no_grad():
         ref = F.linear(R.pooled_features(sd, x), sd['fc0.weight'], sd['fc0.bias'])
         for main_t, cross in (('bf16', None), ('fp16', None), ('bf16', 'exact16'), ('fp16', 'exact16'), ('fp16', 'fp6'), ('fp16', 'fp4'),
                               ('bf16', 'fp6')):
             out = forward(sd, x, main_t, cross)
-            print('main %-5s cross %-8s max|dlogit| = %.2e' % (main_t, cross, float((out - ref).abs().max())))
+            print('main %-5s cross %-8s max|dlogit| = %.2e' % (main_t, cross, float((out - ref).abs().max())), end='')
+            if cross in ('fp4', 'fp6'):
+                out = forward(sd, x, main_t, cross, stored=True)
+                print('   with (hi, q(lo)) storage: %.2e' % float((out - ref).abs().max()), end='')
+            print()
 
 
 if __name__ == '__main__':

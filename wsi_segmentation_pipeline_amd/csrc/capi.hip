@@ -49,6 +49,25 @@ static void bn_fold(const float* g, const float* b, const float* m, const float*
     scale = (double)g[co] / sqrt((double)v[co] + (double)eps);
     shift = (double)b[co] - (double)m[co] * scale;
 }
+// nearest fp4 (e2m1) code of y (round-to-nearest-even on the 1-bit mantissa, saturating), like v_cvt_scalef32_pk_fp4_f32
+static inline unsigned fp4_encode(float y) {
+    const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    const float a = fabsf(y);
+    int best = 7;
+    for (int i = 0; i < 7; ++i) {
+        const float mid = 0.5f * (mag[i] + mag[i + 1]);
+        if (a < mid || (a == mid && (i & 1) == 0)) { best = i; break; }
+    }
+    return (unsigned)best | ((y < 0.f || (y == 0.f && signbit(y))) ? 8u : 0u);
+}
+static inline float f16_round(float x) { return (float)(_Float16)x; }
+static inline uint16_t f16_bits(float x) {
+    const _Float16 hf = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &hf, 2);
+    return u;
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 extern "C" {
@@ -56,17 +75,17 @@ extern "C" {
 int wsi_hip_abi_version(void) { return WSI_HIP_ABI_VERSION; }
 
 size_t wsi_pf_bytes(int n, int h, int w, int c, int planes) {
-    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || planes < 1 || planes > 2) return 0;
-    return (size_t)pf_alloc_pixels(n, h, w) * (size_t)c * planes * 2;
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || planes < 1 || planes > 3) return 0;
+    return (size_t)pf_alloc_pixels(n, h, w) * (size_t)c * (planes == 1 ? 2 : 4);
 }
 long long wsi_pf_pixel_index(int n, int y, int x, int h, int w) {
     return (long long)(w + 2) + (long long)n * (h + 1) * (w + 1) + (long long)y * (w + 1) + x;
 }
 
 size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes) {
-    if (cout % 32 || cin % 64 || (k != 1 && k != 3) || planes < 1 || planes > 2) return 0;
-    // [cout/32][lines][k*k][4 frags][64 lanes][8] bf16, lines = cin*planes/64
-    return (size_t)(cout / 32) * (cin * planes / 64) * k * k * 4 * 64 * 8 * 2;
+    if (cout % 32 || cin % 64 || (k != 1 && k != 3) || planes < 1 || planes > 3) return 0;
+    // [cout/32][lines][k*k][4 frags][64 lanes][16 bytes]; lines = cin/64 (planes 1) or cin/32 (planes 2, 3)
+    return (size_t)(cout / 32) * (planes == 1 ? cin / 64 : cin / 32) * k * k * 4 * 64 * 16;
 }
 
 int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
@@ -74,11 +93,53 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
                      float* bias_out) {
     if (!w || !wpk_out || !bias_out || wsi_prepack_conv_bytes(cout, cin, k, planes) == 0) return WSI_EINVAL;
     uint16_t* o = (uint16_t*)wpk_out;
-    const int NL = cin * planes / 64, NT = k * k;
+    const int NL = planes == 1 ? cin / 64 : cin / 32, NT = k * k;
     for (int co = 0; co < cout; ++co) {
         double sc, sh;
         bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
         bias_out[co] = (float)sh;
+    }
+    if (planes == 3) {
+        // per (cout, line, tap): fp16 hi of the 32 channels; hi4 / lo4 = MX-fp4 of hi / (w - hi) with one E8M0
+        // scale per block.  frag 0/1: fp16 k-steps; frag 2: lanes h=0 carry Wh4, h=1 carry Wl4 (the two K halves
+        // of the MX instruction pair with Xl4 / Xh4); frag 3: dword 0 = that lane's block scale byte.
+        memset(wpk_out, 0, wsi_prepack_conv_bytes(cout, cin, k, planes));
+        for (int nt = 0; nt < cout / 32; ++nt)
+            for (int l = 0; l < NL; ++l)
+                for (int t = 0; t < NT; ++t) {
+                    uint8_t* base = (uint8_t*)wpk_out + (((size_t)nt * NL + l) * NT + t) * 4096;
+                    for (int r = 0; r < 32; ++r) {
+                        const int co = nt * 32 + r;
+                        double sc, sh;
+                        bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+                        float hi[32], lo[32], mh = 0.f, ml = 0.f;
+                        for (int ci = 0; ci < 32; ++ci) {
+                            const float wf = (float)((double)w[(((size_t)co * cin + 32 * l + ci) * k + t / k) * k + t % k] * sc);
+                            hi[ci] = f16_round(wf);
+                            lo[ci] = wf - hi[ci];
+                            mh = fmaxf(mh, fabsf(hi[ci]));
+                            ml = fmaxf(ml, fabsf(lo[ci]));
+                        }
+                        const int sh_b = mx4_scale_byte(mh), sl_b = mx4_scale_byte(ml);
+                        const float ih = sh_b ? 1.0f / mx4_scale_value(sh_b) : 0.f, il = sl_b ? 1.0f / mx4_scale_value(sl_b) : 0.f;
+                        for (int h = 0; h < 2; ++h) {
+                            const int lane = r + 32 * h;
+                            uint16_t* f0 = (uint16_t*)(base + 0 * 1024 + lane * 16);
+                            uint16_t* f1 = (uint16_t*)(base + 1 * 1024 + lane * 16);
+                            for (int j = 0; j < 8; ++j) {
+                                f0[j] = f16_bits(hi[8 * h + j]);
+                                f1[j] = f16_bits(hi[16 + 8 * h + j]);
+                            }
+                            uint8_t* f2 = base + 2 * 1024 + lane * 16;
+                            for (int ci = 0; ci < 32; ++ci) {
+                                const unsigned q = h == 0 ? fp4_encode(hi[ci] * ih) : fp4_encode(lo[ci] * il);
+                                f2[ci >> 1] |= (uint8_t)(q << (4 * (ci & 1)));
+                            }
+                            *(uint32_t*)(base + 3 * 1024 + lane * 16) = (uint32_t)(h == 0 ? sh_b : sl_b);
+                        }
+                    }
+                }
+        return WSI_OK;
     }
     for (int nt = 0; nt < cout / 32; ++nt)
         for (int l = 0; l < NL; ++l)
@@ -245,12 +306,12 @@ int wsi_linear(const float* x, const float* w, const float* bias, float* y, int 
 }
 
 int wsi_pf_pack(const float* in_nchw, void* out_pf, int n, int c, int h, int w, int planes, void* stream) {
-    if (!in_nchw || !out_pf || n <= 0 || c % 64 || planes < 1 || planes > 2) return WSI_EINVAL;
+    if (!in_nchw || !out_pf || n <= 0 || c % 64 || planes < 1 || planes > 3) return WSI_EINVAL;
     return wsi_pf_pack_dispatch(in_nchw, out_pf, pf_geom(n, h, w, c), planes, (hipStream_t)stream);
 }
 
 int wsi_pf_unpack(const void* in_pf, float* out_nchw, int n, int c, int h, int w, int planes, void* stream) {
-    if (!in_pf || !out_nchw || n <= 0 || c % 64 || planes < 1 || planes > 2) return WSI_EINVAL;
+    if (!in_pf || !out_nchw || n <= 0 || c % 64 || planes < 1 || planes > 3) return WSI_EINVAL;
     return wsi_pf_unpack_dispatch(in_pf, out_nchw, pf_geom(n, h, w, c), planes, (hipStream_t)stream);
 }
 

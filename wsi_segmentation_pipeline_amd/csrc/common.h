@@ -58,6 +58,22 @@ static inline __device__ bool pf_is_pixel(const PFGeom& g, int q) {
     return x != g.W && y != g.H;
 }
 
+// Precision / storage modes ("planes" in the C ABI):
+//   1  bf16 single             line = 64 channels x 2 B                              (speed mode)
+//   2  bf16 hi + bf16 lo       line = 32 channels: [hi x32][lo x32]                  (3 MFMA passes)
+//   3  fp16 hi + MX-fp4 cross  line = 32 channels: [hi fp16 x32 | lo4 16 B | hi4 16 B | scale_lo dword.. | scale_hi dword..]
+//      x = hi + lo4*2^(scale_lo-127); the conv is  Wh*Xh (two fp16 MFMAs)  +  [Wh4*Xl4 | Wl4*Xh4] as the two
+//      K halves of ONE v_mfma_scale_f32_32x32x64_f8f6f4 (block scale per 32 channels): 3 instructions per
+//      (tile, line, tap) instead of 6 (tools/sim_mx_numerics.py, tools/probes/mx_*.hip)
+template <int PLANES> struct PFmt {
+    static constexpr int BPC = PLANES == 1 ? 2 : 4;          // bytes per channel in a pixel record
+    static constexpr int CPL = PLANES == 1 ? 64 : 32;        // channels per 128-byte line
+};
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
 struct ConvArgs {
     const void* in;        // PF activations, PLANES planes
     void* out;             // PF activations
@@ -76,6 +92,28 @@ struct ConvArgs {
 
 static inline __device__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// mode 3 helpers ---------------------------------------------------------------------------
+// E8M0 exponent byte s such that amax / 2^(s-127) <= 6 (fp4 e2m1 max); amax == 0 -> 0
+static inline __host__ __device__ int mx4_scale_byte(float amax) {
+    if (!(amax > 0.f)) return 0;
+    const float t = amax * (1.0f / 6.0f);
+    union { float f; unsigned u; } c;
+    c.f = t;
+    int e = (int)((c.u >> 23) & 255) + ((c.u & 0x7fffffu) ? 1 : 0);   // ceil(log2 t) + 127
+    return e < 1 ? 1 : (e > 254 ? 254 : e);
+}
+static inline __host__ __device__ float mx4_scale_value(int s) {
+    union { float f; unsigned u; } c;
+    c.u = (unsigned)s << 23;                                  // 2^(s-127), s in [1,254]
+    return c.f;
+}
+// decode one fp4 (e2m1) nibble
+static inline __host__ __device__ float fp4_value(unsigned n) {
+    const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    const float v = mag[n & 7];
+    return (n & 8) ? -v : v;
 }
 
 // fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative

@@ -21,8 +21,8 @@ template <int MT, int PLANES>
 static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                        const bool (&valid)[MT], int ntile, int lane) {
     const int h = lane >> 5;
-    const size_t pixstride = (size_t)a.go.C * PLANES * 2;
-    const size_t chan_off = (size_t)ntile * (64 * PLANES) + (size_t)(4 * h) * 2;
+    const size_t pixstride = (size_t)a.go.C * PFmt<PLANES>::BPC;
+    const size_t chan_off = (size_t)ntile * (32 * PFmt<PLANES>::BPC) + (size_t)(4 * h) * 2;
     size_t poff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -85,6 +85,75 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
                     *(bf16x4*)op = hi;
                     if constexpr (PLANES == 2) *(bf16x4*)(op + 64) = lo;
                 }
+            }
+        }
+    }
+}
+
+// Mode-3 epilogue (fp16 hi + MX-fp4): per pixel the 32 channels of this wave's n-tile live in lanes
+// l and l^32 (16 registers each): block maxima need one cross-lane exchange; hi4 / lo4 are produced by
+// v_cvt_scalef32_pk_fp4_f32 (RNE, saturating) with the block scales 2^(s-127) (E8M0 bytes stored per line).
+template <int MT>
+static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
+                                                        const bool (&valid)[MT], int ntile, int lane) {
+    const int h = lane >> 5;
+    const size_t pixstride = (size_t)a.go.C * 4;
+    float bias[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * 128;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[mt][r] + bias[r];
+        if (a.resid) {
+            const char* rl = (const char*)a.resid + loff;
+            const unsigned rs = *(const unsigned*)(rl + 96) & 255u;                 // residual's scale_lo
+            const float rscale = rs ? mx4_scale_value((int)rs) : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16x4 rh = *(const f16x4*)(rl + (8 * g + 4 * h) * 2);
+                const unsigned nib = *(const unsigned short*)(rl + 64 + 4 * g + 2 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * g + i] += (float)rh[i] + fp4_value((nib >> (4 * i)) & 15u) * rscale;
+            }
+        }
+        float hi[16], lo[16], mh = 0.f, ml = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (a.relu & 1) v[r] = fmaxf(v[r], 0.f);
+            v[r] = fminf(fmaxf(v[r], -65504.f), 65504.f);
+            hi[r] = (float)(_Float16)v[r];
+            lo[r] = v[r] - hi[r];
+            mh = fmaxf(mh, fabsf(hi[r]));
+            ml = fmaxf(ml, fabsf(lo[r]));
+        }
+        mh = fmaxf(mh, __shfl_xor(mh, 32));
+        ml = fmaxf(ml, __shfl_xor(ml, 32));
+        const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
+        const float fh = sh ? mx4_scale_value(sh) : 1.f, fl = sl ? mx4_scale_value(sl) : 1.f;
+        if (valid[mt] && !(a.relu & 2)) {
+            char* ol = (char*)a.out + loff;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = (_Float16)hi[4 * g + i];
+                *(f16x4*)(ol + (8 * g + 4 * h) * 2) = hv;
+                unsigned ql = 0, qh = 0;
+                ql = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ql, lo[4 * g], lo[4 * g + 1], fl, 0);
+                ql = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ql, lo[4 * g + 2], lo[4 * g + 3], fl, 1);
+                qh = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qh, hi[4 * g], hi[4 * g + 1], fh, 0);
+                qh = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qh, hi[4 * g + 2], hi[4 * g + 3], fh, 1);
+                *(unsigned short*)(ol + 64 + 4 * g + 2 * h) = (unsigned short)ql;
+                *(unsigned short*)(ol + 80 + 4 * g + 2 * h) = (unsigned short)qh;
+            }
+            if (h == 0) {
+                *(unsigned*)(ol + 96) = (unsigned)sl;
+                *(unsigned*)(ol + 112) = (unsigned)sh;
             }
         }
     }
@@ -171,8 +240,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab_kernel(ConvA
     const int q0 = a.gi.G + mtile * BM;
     const int npieces = (BM + 2 * P + 2) * 8;                 // 16-byte pieces in the slab
     const int ntile = nb * WN + wn;
-    const int NC = a.gi.C * PLANES / 64;
-    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
     const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * 9 * 4 * 64 + lane;
 
@@ -237,9 +306,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
     const int mtile = blockIdx.x / nblocks;
     const int q0 = a.go.G + mtile * BM;
     const int ntile = nb * WN + wn;
-    const int NC = a.gi.C * PLANES / 64;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
     const int KS = a.ksize, NT = KS * KS, pad = KS / 2;
-    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * NT * 4 * 64 + lane;
 
     // input pixel (tap 0,0) of each output pixel this thread stages
@@ -321,8 +390,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const int mtile = blockIdx.x / nblocks;
     const int P = a.gi.P;
     const int ntile = nb * WN + wn;
-    const int NC = (a.relu & 128) ? 0 : a.gi.C * PLANES / 64;  // ablation: no main loop, epilogue only
-    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const int NC = (a.relu & 128) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // ablation: no main loop, epilogue only
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     int xoff[MT], qs[MT];                                     // slab-local pixel / PF position of each tile row
     bool valid[MT];
     int slab0, npieces;
@@ -406,7 +475,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
                 else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
                 const bf16x8(&w)[4] = wbuf[t % 3];
                 const bf16x8(&x)[4] = xf[k & 1];
-                if constexpr (PLANES == 2) {
+                if constexpr (PLANES == 3) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), acc[mt], 0, 0, 0);
+                    const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+                    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+                    acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, acc[mt], 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                                              __builtin_bit_cast(i32x4, x[3])[0]);
+                } else if constexpr (PLANES == 2) {
                     acc[mt] = mfma_bf16(w[2], x[0], acc[mt]);   // lo*hi
                     acc[mt] = mfma_bf16(w[3], x[1], acc[mt]);
                     acc[mt] = mfma_bf16(w[0], x[2], acc[mt]);   // hi*lo
@@ -420,7 +496,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             }
         }
     }
-    conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
+    if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
+    else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
 }
 
 template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE>
@@ -480,8 +557,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     const int npix = 4 * BM + 2 * P + 2;
     const int npieces = npix * 8;
     const int ntile = nb * WN + wn;
-    const int NC = a.gi.C * PLANES / 64;
-    const size_t in_pixstride = (size_t)a.gi.C * PLANES * 2;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -608,7 +685,7 @@ template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE>
 static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
     if (a.go.C % (WN * 32) || a.go.P > 34) return WSI_EINVAL;
-    if ((unsigned long long)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * a.gi.C * PLANES * 2 >= 0xffffffffull) return WSI_EINVAL;
+    if ((unsigned long long)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * a.gi.C * PFmt<PLANES>::BPC >= 0xffffffffull) return WSI_EINVAL;
     const int mtiles = (a.go.NS + BM - 1) / BM;
     const int nblocks = a.go.C / (WN * 32);
     const int npieces = (4 * BM + 2 * a.go.P + 2) * 8;
@@ -690,10 +767,12 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(38, 4, 2, 2, 3, true)
 
 int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
+    if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 family implements mode 3
     switch (cfg) {
 
 #define X(id, MT, WM, WN, MINW, DENSE) \
-    case id: return planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
+    case id: return planes == 3 ? launch_slab3<MT, WM, WN, 3, MINW, DENSE>(a, st) \
+                  : planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
         SLAB3_CFGS(X)
 #undef X
 #define X(id, MT, WM, WN, MINW) \
@@ -710,7 +789,8 @@ static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 30 :
 // Host dispatch.  cfg < 0 selects the tuned default.
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     const int cout = a.go.C;
-    if (a.gi.C % 64 || cout % 64 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    if (a.gi.C % 64 || cout % 64 || planes < 1 || planes > 3) return WSI_EINVAL;
+    if (planes == 3 && !(a.ksize == 3 && a.stride == 1)) return WSI_EINVAL;      // mode 3: slab kernels only
     if (a.ksize == 3 && a.stride == 1) {
         if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;
         return wsi_slab_dispatch_cfg(a, planes, cfg < 0 ? slab_default_cfg(a) : cfg, st);

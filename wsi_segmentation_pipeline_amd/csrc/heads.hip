@@ -6,6 +6,45 @@
 //   pf_pack / pf_unpack : f32 NCHW <-> padded-flat bf16 planes (API boundary + tests)
 #include "common.h"
 
+// nearest fp4 (e2m1) code, round-to-nearest-even, saturating (same rule as v_cvt_scalef32_pk_fp4_f32 and the host prepack)
+static __device__ __forceinline__ unsigned fp4_encode_dev(float y) {
+    const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    const float a = fabsf(y);
+    int best = 7;
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+        const float mid = 0.5f * (mag[i] + mag[i + 1]);
+        if (a < mid || (a == mid && (i & 1) == 0)) best = i;
+    }
+    return (unsigned)best | ((__float_as_uint(y) >> 31) ? 8u : 0u);
+}
+
+// mode-3 line codec for one pixel line (32 channels): v[32] -> 128 bytes, and back
+static __device__ void mx_line_encode(const float* v, char* line) {
+    float hi[32], lo[32], mh = 0.f, ml = 0.f;
+    for (int c = 0; c < 32; ++c) {
+        hi[c] = (float)(_Float16)v[c];
+        lo[c] = v[c] - hi[c];
+        mh = fmaxf(mh, fabsf(hi[c]));
+        ml = fmaxf(ml, fabsf(lo[c]));
+    }
+    const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
+    const float ih = sh ? 1.0f / mx4_scale_value(sh) : 0.f, il = sl ? 1.0f / mx4_scale_value(sl) : 0.f;
+    for (int c = 0; c < 32; ++c) ((_Float16*)line)[c] = (_Float16)hi[c];
+    for (int b = 0; b < 16; ++b) {
+        line[64 + b] = (char)(fp4_encode_dev(lo[2 * b] * il) | (fp4_encode_dev(lo[2 * b + 1] * il) << 4));
+        line[80 + b] = (char)(fp4_encode_dev(hi[2 * b] * ih) | (fp4_encode_dev(hi[2 * b + 1] * ih) << 4));
+    }
+    for (int b = 96; b < 128; b += 4) *(unsigned*)(line + b) = 0u;
+    *(unsigned*)(line + 96) = (unsigned)sl;
+    *(unsigned*)(line + 112) = (unsigned)sh;
+}
+static __device__ __forceinline__ float mx_line_decode(const char* line, int c) {     // x = hi + lo4 * 2^(scale_lo-127)
+    const unsigned sl = *(const unsigned*)(line + 96) & 255u;
+    const unsigned nib = ((unsigned)(unsigned char)line[64 + (c >> 1)] >> (4 * (c & 1))) & 15u;
+    return (float)((const _Float16*)line)[c] + (sl ? fp4_value(nib) * mx4_scale_value((int)sl) : 0.f);
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -19,8 +58,18 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const void* in, PFGeom 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* f = (float*)smem;                            // C floats
     const int n = blockIdx.x, tid = threadIdx.x;
-    const size_t pixstride = (size_t)g.C * PLANES * 2;
+    const size_t pixstride = (size_t)g.C * PFmt<PLANES>::BPC;
     const float inv = 1.0f / (float)(g.H * g.W);
+    if constexpr (PLANES == 3) {
+        for (int c = tid; c < g.C; c += 256) {
+            float sm = 0.f;
+            for (int y = 0; y < g.H; ++y)
+                for (int x = 0; x < g.W; ++x)
+                    sm += mx_line_decode((const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * pixstride + (size_t)(c >> 5) * 128, c & 31);
+            f[c] = sm * inv;
+            if (feat) feat[(size_t)n * g.C + c] = sm * inv;
+        }
+    } else
     for (int c4 = tid; c4 < g.C / 4; c4 += 256) {
         const int c = c4 * 4;
         const size_t coff = PLANES == 2 ? (size_t)(c >> 5) * 128 + (c & 31) * 2 : (size_t)c * 2;
@@ -131,6 +180,33 @@ __global__ __launch_bounds__(256) void pf_unpack_kernel(const void* in, float* o
     }
 }
 
+__global__ __launch_bounds__(256) void pf_pack_mx_kernel(const float* in, void* out, PFGeom g) {
+    const long long total = (long long)g.N * g.H * g.W * (g.C / 32);
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int l = (int)(i % (g.C / 32));
+        long long p = i / (g.C / 32);
+        const int x = (int)(p % g.W); p /= g.W;
+        const int y = (int)(p % g.H);
+        const int n = (int)(p / g.H);
+        float v[32];
+        for (int c = 0; c < 32; ++c) v[c] = in[(((size_t)n * g.C + 32 * l + c) * g.H + y) * g.W + x];
+        mx_line_encode(v, (char*)out + (size_t)(g.G + n * g.S + y * g.P + x) * ((size_t)g.C * 4) + (size_t)l * 128);
+    }
+}
+
+__global__ __launch_bounds__(256) void pf_unpack_mx_kernel(const void* in, float* out, PFGeom g) {
+    const long long total = (long long)g.N * g.H * g.W * g.C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        long long p = i / g.C;
+        const int x = (int)(p % g.W); p /= g.W;
+        const int y = (int)(p % g.H);
+        const int n = (int)(p / g.H);
+        const char* line = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * ((size_t)g.C * 4) + (size_t)(c >> 5) * 128;
+        out[(((size_t)n * g.C + c) * g.H + y) * g.W + x] = mx_line_decode(line, c & 31);
+    }
+}
+
 static int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -138,9 +214,11 @@ static int grid_for(long long total) {
 
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
                             float* logits, int planes, hipStream_t st) {
-    if (g.C % 4 || g.N <= 0 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    if (g.C % 4 || g.N <= 0 || planes < 1 || planes > 3 || (planes == 3 && g.C % 32)) return WSI_EINVAL;
     const size_t lds = (size_t)g.C * 4;
-    if (planes == 2)
+    if (planes == 3)
+        hipLaunchKernelGGL(avgpool_fc_kernel<3>, dim3(g.N), dim3(256), lds, st, in, g, w, b, K, feat, logits);
+    else if (planes == 2)
         hipLaunchKernelGGL(avgpool_fc_kernel<2>, dim3(g.N), dim3(256), lds, st, in, g, w, b, K, feat, logits);
     else
         hipLaunchKernelGGL(avgpool_fc_kernel<1>, dim3(g.N), dim3(256), lds, st, in, g, w, b, K, feat, logits);
@@ -156,7 +234,9 @@ int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float
 
 int wsi_pf_pack_dispatch(const float* in, void* out, const PFGeom& g, int planes, hipStream_t st) {
     const long long total = (long long)g.N * g.H * g.W * g.C;
-    if (planes == 2)
+    if (planes == 3)
+        hipLaunchKernelGGL(pf_pack_mx_kernel, dim3(grid_for(total / 32)), dim3(256), 0, st, in, out, g);
+    else if (planes == 2)
         hipLaunchKernelGGL(pf_pack_kernel<2>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
     else
         hipLaunchKernelGGL(pf_pack_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
@@ -165,7 +245,9 @@ int wsi_pf_pack_dispatch(const float* in, void* out, const PFGeom& g, int planes
 
 int wsi_pf_unpack_dispatch(const void* in, float* out, const PFGeom& g, int planes, hipStream_t st) {
     const long long total = (long long)g.N * g.H * g.W * g.C;
-    if (planes == 2)
+    if (planes == 3)
+        hipLaunchKernelGGL(pf_unpack_mx_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
+    else if (planes == 2)
         hipLaunchKernelGGL(pf_unpack_kernel<2>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
     else
         hipLaunchKernelGGL(pf_unpack_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in, out, g);
