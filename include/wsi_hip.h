@@ -10,7 +10,9 @@
  *   - every device function takes a hipStream_t (passed as void*), enqueues asynchronously and
  *     returns 0 or a negative errno (-22 EINVAL bad shape/argument, -14 EFAULT launch failure);
  *     nothing throws, nothing allocates: workspaces are caller-owned
- *   - planes = 2 : bf16x2 split operands, three MFMA passes, meets the 1e-3 logit contract
+ *   - planes = 2 : bf16x2 split operands, three MFMA passes, meets the 1e-3 logit contract (3e-5)
+ *     planes = 3 : fp16 main pass + MX-fp4 block-scaled cross terms (one scale per 32 channels), three MFMA
+ *                  instructions per step instead of six; meets the contract with ~3x margin
  *     planes = 1 : single-pass bf16 (speed mode; logit error ~2e-2)
  *   - "PF" = padded-flat activation layout, see wsi_pf_* below and DESIGN.md
  */

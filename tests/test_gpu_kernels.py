@@ -93,6 +93,7 @@ def test_conv_stride2_and_downsample(dev, shape):
     assert _conv_case(dev, n, cin, cout, h, w, 2, 1, False, False, 2, 5) <= TOL_PARITY
     assert _conv_case(dev, n, cin, cout, h, w, 2, 3, False, True, 1, 6) <= TOL_SPEED
     assert _conv_case(dev, n, cin, cout, h, w, 2, 1, False, False, 1, 7) <= TOL_SPEED
+    assert _conv_case(dev, n, cin, cout, h, w, 2, 3, False, True, 3, 4) <= TOL_MX       # mode 3: slab form only
 
 
 def test_mfma_orientation_asymmetric(dev):
@@ -182,7 +183,7 @@ def test_fused_stride2_block_entry(dev, shape):
     from wsi_segmentation_pipeline_amd import native, engine as E
     n, cin, cout, h, w = shape
     lib = native.load()
-    for planes, tol in ((2, TOL_PARITY), (1, TOL_SPEED)):
+    for planes, tol in ((2, TOL_PARITY), (1, TOL_SPEED), (3, TOL_MX)):
         g = torch.Generator().manual_seed(9)
         x = torch.randn(n, cin, h, w, generator=g).abs_()
         w3 = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
@@ -203,5 +204,9 @@ def test_fused_stride2_block_entry(dev, shape):
         g3 = E.pf_unpack(o3, n, cout, h // 2, w // 2, planes).cpu()
         g1 = E.pf_unpack(o1, n, cout, h // 2, w // 2, planes).cpu()
         assert _rel_err(g3, ref3) <= tol and _rel_err(g1, ref1) <= tol
-        real = E.pf_pack(torch.full_like(g3, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
-        assert not bool((o3.view(torch.int16)[~real] != 0).any()) and not bool((o1.view(torch.int16)[~real] != 0).any())
+        if planes == 3:
+            real = E.pf_pack(torch.ones_like(g3).to(dev), 3).view(-1, 128)[:, :64].ne(0).any(1)
+            assert not bool(o3.view(-1, 128)[~real].ne(0).any()) and not bool(o1.view(-1, 128)[~real].ne(0).any())
+        else:
+            real = E.pf_pack(torch.full_like(g3, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
+            assert not bool((o3.view(torch.int16)[~real] != 0).any()) and not bool((o1.view(torch.int16)[~real] != 0).any())

@@ -114,7 +114,8 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
                         bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
                         float hi[32], lo[32], mh = 0.f, ml = 0.f;
                         for (int ci = 0; ci < 32; ++ci) {
-                            const float wf = (float)((double)w[(((size_t)co * cin + 32 * l + ci) * k + t / k) * k + t % k] * sc);
+                            // ci = K position inside the line; its channel follows the activation line order
+                            const float wf = (float)((double)w[(((size_t)co * cin + 32 * l + mx_line_chan(ci)) * k + t / k) * k + t % k] * sc);
                             hi[ci] = f16_round(wf);
                             lo[ci] = wf - hi[ci];
                             mh = fmaxf(mh, fabsf(hi[ci]));
@@ -164,10 +165,14 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
     return WSI_OK;
 }
 
-size_t wsi_prepack_stem_bytes(int planes) { return (planes < 1 || planes > 2) ? 0 : (size_t)2 * 14 * planes * 64 * 8 * 2; }
+size_t wsi_prepack_stem_bytes(int planes) {
+    if (planes == 3) planes = 2;                       // mode 3 keeps the stem's own arithmetic in bf16 hi/lo
+    return (planes < 1 || planes > 2) ? 0 : (size_t)2 * 14 * planes * 64 * 8 * 2;
+}
 
 int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                      const float* bn_var, float eps, int planes, void* wpk_out, float* bias_out) {
+    if (planes == 3) planes = 2;
     if (!w || !wpk_out || !bias_out || planes < 1 || planes > 2) return WSI_EINVAL;
     uint16_t* o = (uint16_t*)wpk_out;
     for (int co = 0; co < 64; ++co) {
@@ -227,7 +232,7 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
     a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
     a.origins = tile_xy; a.lut = lut; a.wpk = stem_wpk; a.bias = stem_bias; a.out = scratch;
     a.N = n; a.H = h; a.W = w;
-    if (g_stem_fused) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream);
+    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
     return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
@@ -399,7 +404,7 @@ struct TrunkPlan {
 };
 
 static int trunk_plan(int n, int h, int w, int planes, TrunkPlan& p) {
-    if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32 || planes < 1 || planes > 2) return WSI_EINVAL;
+    if (n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32 || planes < 1 || planes > 3) return WSI_EINVAL;
     size_t off = 0;
     p.stem_scratch = off;
     off += align_up((size_t)n * (h / 2) * (w / 2) * 64 * sizeof(float), 256);

@@ -72,6 +72,8 @@ template <int PLANES> struct PFmt {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 struct ConvArgs {
@@ -109,6 +111,29 @@ static inline __host__ __device__ float mx4_scale_value(int s) {
     c.u = (unsigned)s << 23;                                  // 2^(s-127), s in [1,254]
     return c.f;
 }
+// Mode-3 channel order inside a 32-channel line.  The 32x32 MFMA accumulator leaves lane (pixel, h) with the
+// 16 couts 8g + 4h + i (register r = 4g + i): storing them at line positions 16h + r makes every lane's share of
+// the line contiguous (32 B of fp16, 8 B of each fp4 plane), so the epilogue and the residual read move 16-byte
+// pieces.  K order inside a line is free as long as weights and pixels agree: prepack uses the same map.
+static inline __host__ __device__ int mx_line_pos(int c) { return 16 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3); }
+static inline __host__ __device__ int mx_line_chan(int p) { return 8 * ((p & 15) >> 2) + 4 * (p >> 4) + (p & 3); }
+
+// 8 floats -> one dword of fp4 (RNE(v / scale), saturating); the byte selector must be a literal
+static __device__ __forceinline__ unsigned mx4_pack8(const float* v, float scale) {
+    unsigned q = 0u;
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[0], v[1], scale, 0);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[2], v[3], scale, 1);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[4], v[5], scale, 2);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[6], v[7], scale, 3);
+    return q;
+}
+// one dword of fp4 -> 8 floats (value * scale)
+static __device__ __forceinline__ void mx4_unpack8(unsigned q, float scale, float* v) {
+    const f32x2 a = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 0), b = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 1);
+    const f32x2 c = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 2), d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 3);
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1]; v[6] = d[0]; v[7] = d[1];
+}
+
 // decode one fp4 (e2m1) nibble
 static inline __host__ __device__ float fp4_value(unsigned n) {
     const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};

@@ -90,9 +90,10 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
     }
 }
 
-// Mode-3 epilogue (fp16 hi + MX-fp4): per pixel the 32 channels of this wave's n-tile live in lanes
-// l and l^32 (16 registers each): block maxima need one cross-lane exchange; hi4 / lo4 are produced by
-// v_cvt_scalef32_pk_fp4_f32 (RNE, saturating) with the block scales 2^(s-127) (E8M0 bytes stored per line).
+// Mode-3 epilogue (fp16 hi + MX-fp4).  Lane (pixel, h) owns line positions 16h .. 16h+15 (common.h mx_line_pos):
+// 32 contiguous bytes of fp16 and 8 bytes of each fp4 plane.  Block maxima need one exchange with lane^32; the
+// fp4 planes are swapped between the two lanes so each writes one 16-byte piece (h=0: lo4 of all 32, h=1: hi4).
+// Four store instructions per 32x32 tile (2 x 16 B fp16, 16 B fp4, 4 B scale) and four loads for a residual.
 template <int MT>
 static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                         const bool (&valid)[MT], int ntile, int lane) {
@@ -111,50 +112,46 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
         for (int r = 0; r < 16; ++r) v[r] = acc[mt][r] + bias[r];
         if (a.resid) {
             const char* rl = (const char*)a.resid + loff;
+            const f16x8 r0 = *(const f16x8*)(rl + 32 * h), r1 = *(const f16x8*)(rl + 32 * h + 16);
+            const uint2 nib = *(const uint2*)(rl + 64 + 8 * h);                     // lo4 of this lane's 16 positions
             const unsigned rs = *(const unsigned*)(rl + 96) & 255u;                 // residual's scale_lo
             const float rscale = rs ? mx4_scale_value((int)rs) : 0.f;
+            float d[16];
+            mx4_unpack8(nib.x, rscale, d);
+            mx4_unpack8(nib.y, rscale, d + 8);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f16x4 rh = *(const f16x4*)(rl + (8 * g + 4 * h) * 2);
-                const unsigned nib = *(const unsigned short*)(rl + 64 + 4 * g + 2 * h);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[4 * g + i] += (float)rh[i] + fp4_value((nib >> (4 * i)) & 15u) * rscale;
+            for (int r = 0; r < 8; ++r) {
+                v[r] += (float)r0[r] + d[r];
+                v[8 + r] += (float)r1[r] + d[8 + r];
             }
         }
-        float hi[16], lo[16], mh = 0.f, ml = 0.f;
+        float lo[16], mh = 0.f, ml = 0.f;
+        f16x8 hv[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (a.relu & 1) v[r] = fmaxf(v[r], 0.f);
             v[r] = fminf(fmaxf(v[r], -65504.f), 65504.f);
-            hi[r] = (float)(_Float16)v[r];
-            lo[r] = v[r] - hi[r];
-            mh = fmaxf(mh, fabsf(hi[r]));
+            const _Float16 hh = (_Float16)v[r];
+            hv[r >> 3][r & 7] = hh;
+            lo[r] = v[r] - (float)hh;
+            v[r] = (float)hh;                                                       // v now holds hi
+            mh = fmaxf(mh, fabsf(v[r]));
             ml = fmaxf(ml, fabsf(lo[r]));
         }
         mh = fmaxf(mh, __shfl_xor(mh, 32));
         ml = fmaxf(ml, __shfl_xor(ml, 32));
         const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
         const float fh = sh ? mx4_scale_value(sh) : 1.f, fl = sl ? mx4_scale_value(sl) : 1.f;
+        const unsigned ql[2] = {mx4_pack8(lo, fl), mx4_pack8(lo + 8, fl)}, qh[2] = {mx4_pack8(v, fh), mx4_pack8(v + 8, fh)};
+        // lane h=0 keeps lo4 and receives the partner's lo4; lane h=1 keeps hi4 and receives the partner's hi4
+        const unsigned s0 = __shfl_xor(h ? ql[0] : qh[0], 32), s1 = __shfl_xor(h ? ql[1] : qh[1], 32);
+        const u32x4 q4 = h ? u32x4{s0, s1, qh[0], qh[1]} : u32x4{ql[0], ql[1], s0, s1};
         if (valid[mt] && !(a.relu & 2)) {
             char* ol = (char*)a.out + loff;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 hv;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hv[i] = (_Float16)hi[4 * g + i];
-                *(f16x4*)(ol + (8 * g + 4 * h) * 2) = hv;
-                unsigned ql = 0, qh = 0;
-                ql = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ql, lo[4 * g], lo[4 * g + 1], fl, 0);
-                ql = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ql, lo[4 * g + 2], lo[4 * g + 3], fl, 1);
-                qh = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qh, hi[4 * g], hi[4 * g + 1], fh, 0);
-                qh = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qh, hi[4 * g + 2], hi[4 * g + 3], fh, 1);
-                *(unsigned short*)(ol + 64 + 4 * g + 2 * h) = (unsigned short)ql;
-                *(unsigned short*)(ol + 80 + 4 * g + 2 * h) = (unsigned short)qh;
-            }
-            if (h == 0) {
-                *(unsigned*)(ol + 96) = (unsigned)sl;
-                *(unsigned*)(ol + 112) = (unsigned)sh;
-            }
+            *(f16x8*)(ol + 32 * h) = hv[0];
+            *(f16x8*)(ol + 32 * h + 16) = hv[1];
+            *(u32x4*)(ol + 64 + 16 * h) = q4;
+            *(unsigned*)(ol + 96 + 16 * h) = (unsigned)(h ? sh : sl);
         }
     }
 }
@@ -171,6 +168,22 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
         valid[mt] = pf_is_pixel(a.go, qs[mt]);
     }
     conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
+}
+
+template <int MT, int PLANES>
+static __device__ __forceinline__ void conv_epilogue_any(const ConvArgs& a, f32x16 (&acc)[MT], int q_base, int ntile, int lane) {
+    if constexpr (PLANES == 3) {
+        int qs[MT];
+        bool valid[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            qs[mt] = q_base + mt * 32 + (lane & 31);
+            valid[mt] = pf_is_pixel(a.go, qs[mt]);
+        }
+        conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
+    } else {
+        conv_epilogue<MT, PLANES>(a, acc, q_base, ntile, lane);
+    }
 }
 
 // One 128-byte line of K for MT pixel tiles: 4 fragments per operand; the pixel fragments of tile
@@ -369,7 +382,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 //   * pixel fragments are requested one (tap, m-tile) step ahead - including across taps - so the
 //     LDS latency always hides behind six MFMAs;
 //   * a compiler scheduling fence per tap keeps hipcc from hoisting all nine taps' loads.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // DENSE: the tile enumerates REAL pixels only (n, y, x raster order) instead of consecutive PF
 // positions, so no MFMA work is spent on pad positions ((H+1)(W+1)/HW = 27 % at 8x8 maps); the
@@ -659,7 +671,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
                 const bf16x8(&w)[4] = wbuf[t % RING];
                 const bf16x8(&x)[4] = xf[k & 1];
                 f32x16& d = (FUSE && t == 9) ? accd[FUSE ? mt : 0] : acc[mt];
-                if constexpr (PLANES == 2) {
+                if constexpr (PLANES == 3) {
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
+                    const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+                    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+                    d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                                        __builtin_bit_cast(i32x4, x[3])[0]);
+                } else if constexpr (PLANES == 2) {
                     d = mfma_bf16(w[2], x[0], d);
                     d = mfma_bf16(w[3], x[1], d);
                     d = mfma_bf16(w[0], x[2], d);
@@ -673,11 +692,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
             }
         }
     }
-    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
+    conv_epilogue_any<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
     if constexpr (FUSE) {
         ConvArgs a2 = a;
         a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
-        conv_epilogue<MT, PLANES>(a2, accd, q0 + wm * MT * 32, ntile, lane);
+        conv_epilogue_any<MT, PLANES>(a2, accd, q0 + wm * MT * 32, ntile, lane);
     }
 }
 
@@ -702,10 +721,11 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
 
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
 int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
-    if (a.gi.C % 64 || a.go.C % 128 || (planes != 1 && planes != 2)) return WSI_EINVAL;
+    if (a.gi.C % 64 || a.go.C % 128 || planes < 1 || planes > 3) return WSI_EINVAL;
     if (a.go.H * 2 != a.gi.H || a.go.W * 2 != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
     const bool fuse = a.out2 != nullptr;
     if (fuse && (!a.wpk2 || !a.bias2)) return WSI_EINVAL;
+    if (planes == 3) return fuse ? launch_s2slab<4, 1, 4, 3, 2, true>(a, st) : launch_s2slab<4, 1, 4, 3, 2, false>(a, st);
     if (planes == 2) return fuse ? launch_s2slab<4, 1, 4, 2, 2, true>(a, st) : launch_s2slab<4, 1, 4, 2, 2, false>(a, st);
     return fuse ? launch_s2slab<4, 1, 4, 1, 2, true>(a, st) : launch_s2slab<4, 1, 4, 1, 2, false>(a, st);
 }

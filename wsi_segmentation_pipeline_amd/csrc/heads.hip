@@ -22,9 +22,10 @@ static __device__ __forceinline__ unsigned fp4_encode_dev(float y) {
 // mode-3 line codec for one pixel line (32 channels): v[32] -> 128 bytes, and back
 static __device__ void mx_line_encode(const float* v, char* line) {
     float hi[32], lo[32], mh = 0.f, ml = 0.f;
-    for (int c = 0; c < 32; ++c) {
-        hi[c] = (float)(_Float16)v[c];
-        lo[c] = v[c] - hi[c];
+    for (int c = 0; c < 32; ++c) {                        // c = line position (mx_line_pos order)
+        const float t = v[mx_line_chan(c)];
+        hi[c] = (float)(_Float16)t;
+        lo[c] = t - hi[c];
         mh = fmaxf(mh, fabsf(hi[c]));
         ml = fmaxf(ml, fabsf(lo[c]));
     }
@@ -39,7 +40,8 @@ static __device__ void mx_line_encode(const float* v, char* line) {
     *(unsigned*)(line + 96) = (unsigned)sl;
     *(unsigned*)(line + 112) = (unsigned)sh;
 }
-static __device__ __forceinline__ float mx_line_decode(const char* line, int c) {     // x = hi + lo4 * 2^(scale_lo-127)
+static __device__ __forceinline__ float mx_line_decode(const char* line, int chan) {  // x = hi + lo4 * 2^(scale_lo-127)
+    const int c = mx_line_pos(chan);
     const unsigned sl = *(const unsigned*)(line + 96) & 255u;
     const unsigned nib = ((unsigned)(unsigned char)line[64 + (c >> 1)] >> (4 * (c & 1))) & 15u;
     return (float)((const _Float16*)line)[c] + (sl ? fp4_value(nib) * mx4_scale_value((int)sl) : 0.f);

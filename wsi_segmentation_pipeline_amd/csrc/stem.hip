@@ -187,7 +187,8 @@ constexpr int SP_COLS = 68;                  // input columns per strip (2*31 + 
 constexpr int SP_RING = 16;                  // ring rows
 constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
 
-template <int PLANES>
+// PLANES = arithmetic of the stem itself (1: bf16, 2: bf16 hi/lo 3-pass); OUT = output line format (1, 2 or 3)
+template <int PLANES, int OUT>
 __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const StemArgs& a = A.s;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     for (int r = 0; r < 16; ++r) carry[r] = 0.f;
     const bool col_ok = (c0 + l31) >= 0 && (c0 + l31) < Wc && l31 < 31;
     const int lc = l31 < 31 ? l31 : 30;                                 // lane 31 is idle: keep its reads inside the row
-    const size_t pixstride = (size_t)64 * PLANES * 2;
+    const size_t pixstride = (size_t)64 * PFmt<OUT>::BPC;
     PFGeom go = pf_geom(a.N, Hp, Wp, 64);
 
     for (int py = py0 - 1; py < py1; ++py) {
@@ -298,8 +299,36 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], fmaxf(__shfl_up(v[r], 1), __shfl_down(v[r], 1)));
             const int j = (l31 - 1) >> 1, px = px0 + j;
-            if ((l31 & 1) && l31 <= 29 && px < Wp) {
-                char* o = (char*)A.out_pf + (size_t)(go.G + n * go.S + py * go.P + px) * pixstride;
+            const bool store = (l31 & 1) && l31 <= 29 && px < Wp;
+            char* o = (char*)A.out_pf + (size_t)(go.G + n * go.S + py * go.P + (store ? px : 0)) * pixstride;
+            if constexpr (OUT == 3) {
+                // fp16 hi + MX-fp4 (hi4, lo4) with one scale per 32-channel line; the line's channels sit in lanes l, l^32
+                float hi[16], lo[16], mh = 0.f, ml = 0.f;
+                f16x8 hv[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const _Float16 hh = (_Float16)fminf(v[r], 65504.f);
+                    hv[r >> 3][r & 7] = hh;
+                    hi[r] = (float)hh;
+                    lo[r] = fminf(v[r], 65504.f) - hi[r];
+                    mh = fmaxf(mh, fabsf(hi[r]));
+                    ml = fmaxf(ml, fabsf(lo[r]));
+                }
+                mh = fmaxf(mh, __shfl_xor(mh, 32));
+                ml = fmaxf(ml, __shfl_xor(ml, 32));
+                const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
+                const float fh = sh ? mx4_scale_value(sh) : 1.f, fl = sl ? mx4_scale_value(sl) : 1.f;
+                const unsigned ql[2] = {mx4_pack8(lo, fl), mx4_pack8(lo + 8, fl)}, qh[2] = {mx4_pack8(hi, fh), mx4_pack8(hi + 8, fh)};
+                const unsigned s0 = __shfl_xor(h ? ql[0] : qh[0], 32), s1 = __shfl_xor(h ? ql[1] : qh[1], 32);
+                const u32x4 q4 = h ? u32x4{s0, s1, qh[0], qh[1]} : u32x4{ql[0], ql[1], s0, s1};
+                if (store) {                                                        // line order: common.h mx_line_pos
+                    char* ol = o + wave * 128;
+                    *(f16x8*)(ol + 32 * h) = hv[0];
+                    *(f16x8*)(ol + 32 * h + 16) = hv[1];
+                    *(u32x4*)(ol + 64 + 16 * h) = q4;
+                    *(unsigned*)(ol + 96 + 16 * h) = (unsigned)(h ? sh : sl);
+                }
+            } else if (store) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 hi, lo;
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                         lo[i] = (__bf16)(v[4 * g + i] - (float)hi[i]);
                     }
                     const int c = wave * 32 + 8 * g + 4 * h;
-                    if constexpr (PLANES == 2) {
+                    if constexpr (OUT == 2) {
                         *(bf16x4*)(o + wave * 128 + (8 * g + 4 * h) * 2) = hi;
                         *(bf16x4*)(o + wave * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
                     } else {
@@ -323,17 +352,19 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
 }
 
 int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st) {
-    if (a.H % 4 || a.W % 4 || a.N <= 0 || (planes != 1 && planes != 2) || rows_per_seg <= 0) return WSI_EINVAL;
+    if (a.H % 4 || a.W % 4 || a.N <= 0 || planes < 1 || planes > 3 || rows_per_seg <= 0) return WSI_EINVAL;
     StemPoolArgs A;
     A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg;
     const int Hp = a.H / 4, Wp = a.W / 4;
     const long long grid = (long long)a.N * ((Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
-    const size_t lds = (size_t)planes * SP_PLANE;
-    if (planes == 2)
-        hipLaunchKernelGGL(stem_pool_kernel<2>, dim3((int)grid), dim3(128), lds, st, A);
+    const size_t lds = (size_t)(planes == 1 ? 1 : 2) * SP_PLANE;
+    if (planes == 3)                                  // stem arithmetic stays bf16 hi/lo (its weights are packed that way)
+        hipLaunchKernelGGL((stem_pool_kernel<2, 3>), dim3((int)grid), dim3(128), lds, st, A);
+    else if (planes == 2)
+        hipLaunchKernelGGL((stem_pool_kernel<2, 2>), dim3((int)grid), dim3(128), lds, st, A);
     else
-        hipLaunchKernelGGL(stem_pool_kernel<1>, dim3((int)grid), dim3(128), lds, st, A);
+        hipLaunchKernelGGL((stem_pool_kernel<1, 1>), dim3((int)grid), dim3(128), lds, st, A);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 

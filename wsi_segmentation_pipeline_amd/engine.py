@@ -11,7 +11,7 @@ import torch
 from . import native
 
 BN_EPS = 1e-5                                   # nn.BatchNorm2d default (reference resnets_shift.py:117)
-PARITY, SPEED = 2, 1                            # planes: bf16x2 split (3 MFMA passes) / single bf16
+PARITY, SPEED, MX = 2, 1, 3                     # planes: bf16x2 split (3 passes) / single bf16 / fp16 + MX-fp4 cross terms
 
 
 def _np_ptr(a):
@@ -59,8 +59,8 @@ class TrunkEngine:
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('TrunkEngine needs a GPU device, got %s' % device)
-        if planes not in (1, 2):
-            raise ValueError('planes must be 1 (speed) or 2 (parity)')
+        if planes not in (1, 2, 3):
+            raise ValueError('planes must be 1 (speed), 2 (parity, bf16 split) or 3 (parity, fp16 + MX-fp4)')
         self.planes = planes
         self.max_batch = int(max_batch)
         # batches of one call are spread round-robin over `streams` HIP streams (own workspace each), so a
