@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsi_segmentation_pipeline_amd import engine as E, native  # noqa: E402
 
 SHAPES = [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]      # (C, H, W) for 256x256 patches
-NCFG = 39
+NCFG = 54
 
 
 def main():
@@ -57,7 +57,7 @@ def main():
         if not valid:
             continue
         ref = outs[valid[0]]
-        same = {cfg: bool(torch.equal(outs[cfg], ref)) for cfg in valid}
+        same = {cfg: bool(torch.equal(outs[cfg], ref)) for cfg in valid}            # (ablation cfgs 50-53 differ by design)
         masks = [int(v) for v in args.ablate.split(',')]
         valid = [(cfg, mk) for cfg in valid for mk in masks]
         times = {cfg: [] for cfg in valid}

@@ -151,7 +151,8 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
             *(f16x8*)(ol + 32 * h) = hv[0];
             *(f16x8*)(ol + 32 * h + 16) = hv[1];
             *(u32x4*)(ol + 64 + 16 * h) = q4;
-            *(unsigned*)(ol + 96 + 16 * h) = (unsigned)(h ? sh : sl);
+            const unsigned sc = (unsigned)(h ? sh : sl);                          // replicated: the whole 128-byte line is written
+            *(u32x4*)(ol + 96 + 16 * h) = u32x4{sc, sc, sc, sc};              // (no partial-line writes), readers pick any dword
         }
     }
 }
@@ -218,6 +219,12 @@ static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8
 // LDS byte offset of slot-pair base for slab-local pixel Pl and lane half h (swizzled):
 // slot s = 2f + h is stored at slot s ^ ((Pl>>1)&7); fragment f is reached by XOR (f<<5).
 static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128 + ((h ^ ((Pl >> 1) & 7)) << 4); }
+// Mode 3: the block-scale dword of pixel Pl (slot 6 + h, replicated in all four dwords of the slot).  Reading dword
+// (Pl & 1) + 2 * ((Pl >> 4) & 1) spreads 32 consecutive pixels over all 32 banks of a ds_read_b32.
+static __device__ __forceinline__ bf16x8 lds_xscale(const char* smem, int base, int Pl) {
+    const unsigned sc = *(const unsigned*)(smem + (base ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1)));
+    return __builtin_bit_cast(bf16x8, u32x4{sc, 0u, 0u, 0u});
+}
 
 // --------------------------------------------------------------------------------------------
 // 16-byte LDS-DMA: lane i writes LDS [lds_wave_base + 16*i] from its own global address.
@@ -387,7 +394,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 // positions, so no MFMA work is spent on pad positions ((H+1)(W+1)/HW = 27 % at 8x8 maps); the
 // slab is still the contiguous range from the first to the last pixel's neighbourhood and each
 // lane simply carries its own slab offset.
-template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE>
+// ABL: compile-time ablation for bottleneck studies (tools/tune_conv.py cfg 50-53): 8 = no MFMA, 16 = no weight
+// prefetch (stale registers), 32 = no pixel-fragment LDS reads (stale registers).  0 in every shipped configuration.
+template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
@@ -453,7 +462,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     auto xload = [&](bf16x8(&x)[4], int Pl) {
         const int base = lds_xbase(Pl, h);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+        for (int f = 0; f < (PLANES == 3 ? 3 : 4); ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+        if constexpr (PLANES == 3) x[3] = lds_xscale(smem, base, Pl);
     };
 
     for (int c = 0; c < NC; ++c) {
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             asm volatile("" ::: "memory");                    // scheduling fence: keep later taps' loads below
-            if (t < 8) wload(wbuf[(t + 1) % 3], sline + (t + 1) * 4096);
+            if (t < 8 && !(ABL & 16)) wload(wbuf[(t + 1) % 3], sline + (t + 1) * 4096);
             asm volatile("" ::: "memory");                    // ...and keep THIS prefetch above the tap's MFMAs: without
                                                               // it hipcc sinks the loads to the end of the tap (distance 0)
             const int toff = (t / 3) * Pc + (t % 3);
@@ -483,11 +493,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int k = t * MT + mt;
-                if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
-                else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                if constexpr (!(ABL & 32)) {
+                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
+                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                }
                 const bf16x8(&w)[4] = wbuf[t % 3];
                 const bf16x8(&x)[4] = xf[k & 1];
-                if constexpr (PLANES == 3) {
+                if constexpr (ABL & 8) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[mt][f] += (float)w[f][0] * (float)x[f][0];   // keeps the loads alive
+                } else if constexpr (PLANES == 3) {
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), acc[mt], 0, 0, 0);
                     const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
@@ -512,7 +527,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
 }
 
-template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0>
 static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
     if (a.go.C % (WN * 32)) return WSI_EINVAL;
@@ -529,12 +544,207 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     }
     const size_t lds = (size_t)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE>;
+    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE, ABL>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
     hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+// --------------------------------------------------------------------------------------------
+// Streamed form of the dense slab kernel: a PERSISTENT workgroup walks tiles blockIdx.x, +gridDim.x, ...
+// and treats (tile, 128-byte line) pairs as one stream of work items.  Two slab buffers: while item i
+// is multiplied out of buffer i&1, the slab of item i+1 (the next line, or line 0 of the NEXT tile) is
+// fetched by LDS-DMA into the other buffer, in chunks issued after each tap's weight prefetch (VMEM
+// completes in order: a chunk issued behind the weights of tap t+1 is only waited for by tap t+2's
+// weights, so it has two taps of MFMA time, plus the other resident waves, to land).  The epilogue of
+// a tile runs while the first slab of the next tile is already in flight.  One barrier per item.
+template <int MT, int WM, int WN, int PLANES, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(ConvArgs a, int mtiles, int bufbytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = WM * MT * 32;
+    constexpr int NTHREADS = WM * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    const int total = mtiles * nblocks;
+    const int P = a.gi.P;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
+    const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
+    const int nchunk = bufbytes / (NTHREADS * 16);
+    const int cpt = (nchunk + 5) / 6;                         // DMA chunks per tap: all issued by tap 5
+    auto pos = [&](int i) {
+        const int n = i / HW, rem = i - n * HW;
+        const int y = rem / a.gi.W, x = rem - y * a.gi.W;
+        return a.gi.G + n * a.gi.S + y * P + x;
+    };
+    auto tile_slab = [&](int tile, int& slab0, int& npieces) {
+        const int i0 = (tile / nblocks) * BM, i1 = min(i0 + BM, R) - 1;
+        slab0 = pos(i0) - P - 1;
+        npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
+    };
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (a.go.C / 32) * NC * 9 * 4096, 0x00020000);
+    const int wvoff = lane * 16;
+    auto wload = [&](bf16x8(&w)[4], int soff) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            w[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + f * 1024, soff, 0));
+    };
+    // chunk j of a slab: 16-byte piece i = j*NTHREADS + tid, source swizzled so LDS piece i holds slot (i&7)^((Pl>>1)&7)
+    auto dma_chunk = [&](int j, const char* src, char* dst, int npieces) {
+        const int i0 = wave * 64 + j * NTHREADS;
+        if (i0 < npieces) {
+            const int i = i0 + lane;
+            const int Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+            dma16(src + (size_t)Pl * in_pixstride + sl * 16, dst + (size_t)i0 * 16);
+        }
+    };
+
+    int tile = blockIdx.x;                                    // host launches gridDim.x <= total
+    int slab0, npieces;
+    tile_slab(tile, slab0, npieces);
+    for (int j = 0; j < nchunk; ++j) dma_chunk(j, (const char*)a.in + (size_t)slab0 * in_pixstride, smem, npieces);
+    bf16x8 wbuf[3][4], xf[2][4];
+    int item = 0;
+    {
+        const int ntile0 = (tile % nblocks) * WN + wn;
+        wload(wbuf[0], ntile0 * NC * 9 * 4096);
+    }
+    for (;;) {
+        const int ntile = (tile % nblocks) * WN + wn;
+        int xoff[MT], qs[MT];
+        bool valid[MT];
+        {
+            const int i0 = (tile / nblocks) * BM, i1 = min(i0 + BM, R) - 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+                valid[mt] = i < R;
+                qs[mt] = pos(valid[mt] ? i : i1);
+                xoff[mt] = qs[mt] - slab0 - (P + 1);
+            }
+        }
+        const int tn = tile + gridDim.x;
+        const bool more = tn < total;
+        int slab0_n = 0, npieces_n = 0;
+        if (more) tile_slab(tn, slab0_n, npieces_n);
+        const int wnext_tile = more ? ((tn % nblocks) * WN + wn) * NC * 9 * 4096 : 0;
+
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+        for (int c = 0; c < NC; ++c, ++item) {
+            const char* sb = smem + (size_t)(item & 1) * bufbytes;
+            char* nbuf = smem + (size_t)((item + 1) & 1) * bufbytes;
+            const bool lastc = c == NC - 1;
+            const char* nsrc = (const char*)a.in + (size_t)(lastc ? slab0_n : slab0) * in_pixstride + (lastc ? 0 : (c + 1) * 128);
+            const int np_next = lastc ? (more ? npieces_n : 0) : npieces;
+            const int wline = (ntile * NC + c) * 9 * 4096;
+            const int wnext = lastc ? wnext_tile : wline + 9 * 4096;
+            int Pc = P;                                       // opaque per item (see slab3 kernel)
+            asm volatile("" : "+s"(Pc));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this item's slab (and tap-0 weights) have landed
+            __syncthreads();                                  // ...for every wave; the other buffer is free again
+            auto xload = [&](bf16x8(&x)[4], int Pl) {
+                const int base = lds_xbase(Pl, h);
+#pragma unroll
+                for (int f = 0; f < (PLANES == 3 ? 3 : 4); ++f) x[f] = *(const bf16x8*)(sb + (base ^ (f << 5)));
+                if constexpr (PLANES == 3) x[3] = lds_xscale(sb, base, Pl);
+            };
+            xload(xf[0], xoff[0]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                asm volatile("" ::: "memory");
+                if (t < 8) wload(wbuf[(t + 1) % 3], wline + (t + 1) * 4096);
+                else if (np_next) wload(wbuf[0], wnext);      // tap 0 of the next item
+                if (t < 6)
+                    for (int jj = 0; jj < cpt; ++jj) dma_chunk(t * cpt + jj, nsrc, nbuf, np_next);
+                asm volatile("" ::: "memory");
+                const int toff = (t / 3) * Pc + (t % 3);
+                const int toff_next = ((t + 1) / 3) * Pc + ((t + 1) % 3);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int k = t * MT + mt;
+                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
+                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                    const bf16x8(&w)[4] = wbuf[t % 3];
+                    const bf16x8(&x)[4] = xf[k & 1];
+                    if constexpr (PLANES == 3) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), acc[mt], 0, 0, 0);
+                        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+                        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+                        acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, acc[mt], 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                                                  __builtin_bit_cast(i32x4, x[3])[0]);
+                    } else if constexpr (PLANES == 2) {
+                        acc[mt] = mfma_bf16(w[2], x[0], acc[mt]);
+                        acc[mt] = mfma_bf16(w[3], x[1], acc[mt]);
+                        acc[mt] = mfma_bf16(w[0], x[2], acc[mt]);
+                        acc[mt] = mfma_bf16(w[1], x[3], acc[mt]);
+                        acc[mt] = mfma_bf16(w[0], x[0], acc[mt]);
+                        acc[mt] = mfma_bf16(w[1], x[1], acc[mt]);
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(w[f], x[f], acc[mt]);
+                    }
+                }
+            }
+        }
+        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
+        else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
+        if (!more) break;
+        tile = tn;
+        slab0 = slab0_n;
+        npieces = npieces_n;
+    }
+}
+
+static int g_num_cus = 0;
+template <int MT, int WM, int WN, int PLANES, int MINW>
+static int launch_stream(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
+    if (a.go.C % (WN * 32)) return WSI_EINVAL;
+    const int nblocks = a.go.C / (WN * 32);
+    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+    const int mtiles = (int)((R + BM - 1) / BM);
+    // exact largest slab over the tiles of one image period (tile starts repeat with period lcm(BM, H*W) pixels)
+    const int HW = a.gi.H * a.gi.W;
+    auto pos = [&](long long i) { const long long n = i / HW, rem = i - n * HW; return (long long)a.gi.G + n * a.gi.S + (rem / a.gi.W) * a.gi.P + rem % a.gi.W; };
+    long long maxpix = 0;
+    const int scan = mtiles < 4 * HW ? mtiles : 4 * HW;      // BM*HW pixels cover every phase of (tile start mod H*W)
+    for (int m = 0; m < scan; ++m) {
+        const long long i0 = (long long)m * BM, i1 = (i0 + BM < R ? i0 + BM : R) - 1;
+        const long long px = pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1;
+        if (px > maxpix) maxpix = px;
+    }
+    { const long long i0 = (long long)(mtiles - 1) * BM, i1 = R - 1; const long long px = pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1; if (px > maxpix) maxpix = px; }
+    const int bufbytes = (int)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    const size_t lds = (size_t)2 * bufbytes;
+    if (lds > 160 * 1024) return WSI_EINVAL;
+    auto k = conv3x3s1_stream_kernel<MT, WM, WN, PLANES, MINW>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return WSI_EINVAL;
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return WSI_EFAULT;
+        g_num_cus = pr.multiProcessorCount;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k, NTHREADS, lds) != hipSuccess || occ < 1) return WSI_EINVAL;
+    const long long total = (long long)mtiles * nblocks;
+    const long long resident = (long long)g_num_cus * occ;
+    const int grid = (int)(total < resident ? total : resident);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a, mtiles, bufbytes);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
@@ -628,7 +838,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     auto xload = [&](bf16x8(&x)[4], int Pl) {
         const int base = lds_xbase(Pl, h);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+        for (int f = 0; f < (PLANES == 3 ? 3 : 4); ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+        if constexpr (PLANES == 3) x[3] = lds_xscale(smem, base, Pl);
     };
     // LDS pixel offset of tap t for tile row 0: region base + back + dy*P + dx
     auto tap_off = [&](int t, int Pc) {
@@ -719,12 +930,17 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+int g_s2_small_tiles = 0;
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
 int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
     if (a.gi.C % 64 || a.go.C % 128 || planes < 1 || planes > 3) return WSI_EINVAL;
     if (a.go.H * 2 != a.gi.H || a.go.W * 2 != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
     const bool fuse = a.out2 != nullptr;
     if (fuse && (!a.wpk2 || !a.bias2)) return WSI_EINVAL;
+    if (g_s2_small_tiles) {                                  // 64-pixel tiles: smaller slabs, more workgroups per CU
+        if (planes == 3) return fuse ? launch_s2slab<2, 1, 4, 3, 3, true>(a, st) : launch_s2slab<2, 1, 4, 3, 3, false>(a, st);
+        if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 3, true>(a, st) : launch_s2slab<2, 1, 4, 2, 3, false>(a, st);
+    }
     if (planes == 3) return fuse ? launch_s2slab<4, 1, 4, 3, 2, true>(a, st) : launch_s2slab<4, 1, 4, 3, 2, false>(a, st);
     if (planes == 2) return fuse ? launch_s2slab<4, 1, 4, 2, 2, true>(a, st) : launch_s2slab<4, 1, 4, 2, 2, false>(a, st);
     return fuse ? launch_s2slab<4, 1, 4, 1, 2, true>(a, st) : launch_s2slab<4, 1, 4, 1, 2, false>(a, st);
@@ -782,13 +998,39 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(30, 4, 1, 4, 2, true) \
     X(31, 4, 2, 2, 2, true) \
     X(32, 2, 2, 4, 3, true) \
+    X(33, 8, 1, 4, 2, true) \
+    X(34, 8, 1, 2, 2, true) \
+    X(35, 8, 2, 2, 2, true) \
     X(36, 4, 2, 4, 2, true) \
     X(37, 4, 1, 4, 3, true) \
     X(38, 4, 2, 2, 3, true)
 
+// streamed persistent variants
+#define STREAM_CFGS(X) \
+    X(40, 4, 1, 4, 2) \
+    X(41, 4, 2, 2, 2) \
+    X(42, 4, 1, 2, 2) \
+    X(43, 2, 2, 2, 3) \
+    X(44, 4, 1, 4, 3) \
+    X(45, 2, 2, 4, 3) \
+    X(46, 4, 1, 2, 3)
+
 int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
-    if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 family implements mode 3
+    if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 / stream families implement mode 3
+    if (cfg >= 50 && cfg <= 53 && planes == 3) {             // ablation builds of cfg 30 (bottleneck studies only)
+        switch (cfg) {
+        case 50: return launch_slab3<4, 1, 4, 3, 2, true, 16>(a, st);
+        case 51: return launch_slab3<4, 1, 4, 3, 2, true, 32>(a, st);
+        case 52: return launch_slab3<4, 1, 4, 3, 2, true, 48>(a, st);
+        case 53: return launch_slab3<4, 1, 4, 3, 2, true, 8>(a, st);
+        }
+    }
     switch (cfg) {
+#define X(id, MT, WM, WN, MINW) \
+    case id: return planes == 3 ? launch_stream<MT, WM, WN, 3, MINW>(a, st) \
+                  : planes == 2 ? launch_stream<MT, WM, WN, 2, MINW>(a, st) : launch_stream<MT, WM, WN, 1, MINW>(a, st);
+        STREAM_CFGS(X)
+#undef X
 
 #define X(id, MT, WM, WN, MINW, DENSE) \
     case id: return planes == 3 ? launch_slab3<MT, WM, WN, 3, MINW, DENSE>(a, st) \

@@ -36,9 +36,10 @@ static __device__ void mx_line_encode(const float* v, char* line) {
         line[64 + b] = (char)(fp4_encode_dev(lo[2 * b] * il) | (fp4_encode_dev(lo[2 * b + 1] * il) << 4));
         line[80 + b] = (char)(fp4_encode_dev(hi[2 * b] * ih) | (fp4_encode_dev(hi[2 * b + 1] * ih) << 4));
     }
-    for (int b = 96; b < 128; b += 4) *(unsigned*)(line + b) = 0u;
-    *(unsigned*)(line + 96) = (unsigned)sl;
-    *(unsigned*)(line + 112) = (unsigned)sh;
+    for (int b = 0; b < 16; b += 4) {                     // scales replicated over their 16-byte slots
+        *(unsigned*)(line + 96 + b) = (unsigned)sl;
+        *(unsigned*)(line + 112 + b) = (unsigned)sh;
+    }
 }
 static __device__ __forceinline__ float mx_line_decode(const char* line, int chan) {  // x = hi + lo4 * 2^(scale_lo-127)
     const int c = mx_line_pos(chan);

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                     *(f16x8*)(ol + 32 * h) = hv[0];
                     *(f16x8*)(ol + 32 * h + 16) = hv[1];
                     *(u32x4*)(ol + 64 + 16 * h) = q4;
-                    *(unsigned*)(ol + 96 + 16 * h) = (unsigned)(h ? sh : sl);
+                    const unsigned sc = (unsigned)(h ? sh : sl);
+                    *(u32x4*)(ol + 96 + 16 * h) = u32x4{sc, sc, sc, sc};
                 }
             } else if (store) {
 #pragma unroll
