@@ -48,6 +48,12 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
 size_t wsi_prepack_stem_bytes(int planes);
 int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                      const float* bn_var, float eps, int planes, void* wpk_out, float* bias_out);
+/* Stem weights for u8 slide input (planes >= 2): the ToTensor + Normalize transform is folded in, so the kernel
+ * multiplies the exact integers x - round(255 mean[c]) (one fp16 plane) by fp16 hi/lo weights: two MFMA passes
+ * instead of three and no per-pixel table look-up.  Same byte size as wsi_prepack_stem_bytes(2). */
+int wsi_prepack_stem_u8(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                        const float* bn_var, float eps, const float mean[3], const float std_[3], int planes,
+                        void* wpk_out, float* bias_out);
 /* 3x256 table of (u8/255 - mean[c]) / std[c] evaluated in fp32 exactly like torchvision
  * ToTensor + Normalize (utils/preprocessing.py:209-212, myargs.py:127-130). */
 int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_out /* [3][256] */);
@@ -58,12 +64,15 @@ int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_ou
  * scratch: n*(h/2)*(w/2)*64 floats.  out_pf: PF (h/4, w/4, 64). */
 int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
                                      int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                                     const void* stem_wpk, const float* stem_bias, int n, int h, int w,
-                                     float* scratch, void* out_pf, int planes, void* stream);
+                                     const void* stem_wpk, const float* stem_bias,
+                                     const void* stem_wpk_u8 /* wsi_prepack_stem_u8 output or NULL */,
+                                     const float* stem_bias_u8, const float* norm_mean_std /* HOST: mean[3], std[3] */,
+                                     int n, int h, int w, float* scratch, void* out_pf, int planes, void* stream);
 
 /* tuning / A-B hook: fused = 1 (default) runs the single fused stem+maxpool kernel (no fp32
- * intermediate; scratch unused), fused = 0 the two-kernel form; rows_per_seg = pooled rows per
- * workgroup of the fused kernel (default 32).  Process-wide. */
+ * intermediate; scratch unused), fused = 0 the two-kernel form, fused = 2 the fused kernel with the table
+ * look-up arithmetic even when u8 weights are supplied; rows_per_seg = pooled rows per workgroup of the
+ * fused kernel (default 32).  Process-wide. */
 int wsi_stem_set_mode(int fused, int rows_per_seg);
 
 /* ---- conv + folded BN (+ residual) (+ ReLU) (resnets_shift.py:49-65, 19-27) -------------------
@@ -107,6 +116,8 @@ int wsi_pf_unpack(const void* in_pf, float* out_nchw, int n, int c, int h, int w
  * predict_tumorbed(mode='cls') (utils/eval.py:196-198).  All pointers device memory. */
 typedef struct {
     const void* stem_w;   const float* stem_b;
+    const void* stem_w_u8; const float* stem_b_u8;     /* wsi_prepack_stem_u8 (u8 slide input) or NULL */
+    float norm[6];                                     /* mean[3], std[3] of the transform folded into stem_w_u8 */
     const void* conv_w[16]; const float* conv_b[16];   /* layerL.B.convK at index (L-1)*4 + B*2 + (K-1) */
     const void* down_w[3];  const float* down_b[3];    /* layer2..4 .0.downsample */
     const float* head_w;  const float* head_b;  int head_k;  /* Linear(512 -> head_k) or NULL */

@@ -201,6 +201,48 @@ int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bia
     return WSI_OK;
 }
 
+// Stem weights for the exact-u8 path: W' = W * bn_scale / (255 std[c]) * 2^8 as fp16 hi + fp16 lo (hi + lo == W' to
+// ~2^-22), bias' = bn_shift + sum_taps W * bn_scale / (255 std[c]) * (round(255 mean[c]) - 255 mean[c]), so that
+// sum W' (x - round(255 mean)) 2^-8 + bias' == conv(W, (x/255 - mean)/std) * bn_scale + bn_shift.  planes must be >= 2.
+int wsi_prepack_stem_u8(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                        const float* bn_var, float eps, const float mean[3], const float std_[3], int planes,
+                        void* wpk_out, float* bias_out) {
+    if (!w || !wpk_out || !bias_out || !mean || !std_ || planes < 2 || planes > 3) return WSI_EINVAL;
+    uint16_t* o = (uint16_t*)wpk_out;
+    double fold[3], dmean[3];
+    for (int c = 0; c < 3; ++c) {
+        fold[c] = 1.0 / (255.0 * (double)std_[c]);
+        dmean[c] = (double)lrintf(255.0f * mean[c]) - 255.0 * (double)mean[c];
+    }
+    for (int co = 0; co < 64; ++co) {
+        double sc, sh;
+        bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+        double b = sh;
+        for (int c = 0; c < 3; ++c)
+            for (int t = 0; t < 49; ++t) b += (double)w[((size_t)co * 3 + c) * 49 + t] * sc * fold[c] * dmean[c];
+        bias_out[co] = (float)b;
+    }
+    for (int nt = 0; nt < 2; ++nt)
+        for (int s = 0; s < 14; ++s)
+            for (int p = 0; p < 2; ++p) {
+                uint16_t* frag = o + ((size_t)(nt * 14 + s) * 2 + p) * 512;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = nt * 32 + (lane & 31), h = lane >> 5;
+                    double sc, sh;
+                    bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+                    for (int j = 0; j < 8; ++j) {
+                        const int kh = s >> 1, kw = (s & 1) * 4 + 2 * h + (j >> 2), c = j & 3;
+                        double wd = 0.0;
+                        if (kw < 7 && c < 3) wd = (double)w[(((size_t)co * 3 + c) * 7 + kh) * 7 + kw] * sc * fold[c] * 256.0;
+                        const float hi = f16_round((float)wd);
+                        const float lo = f16_round((float)(wd - (double)hi));
+                        frag[lane * 8 + j] = f16_bits(p ? lo : hi);
+                    }
+                }
+            }
+    return WSI_OK;
+}
+
 int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_out) {
     if (!mean || !std_ || !lut_out) return WSI_EINVAL;
     for (int c = 0; c < 3; ++c)
@@ -214,16 +256,18 @@ int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_ou
 
 // ------------------------------------------------------------------------------------ single ops
 static int g_stem_fused = 1, g_stem_rows = 32;       // fused stem+maxpool kernel; pooled rows per workgroup
+static int g_stem_u8x = 1;                            // exact-u8 arithmetic when the caller supplies its weights (A/B: fused = 2 disables)
 
 int wsi_stem_set_mode(int fused, int rows_per_seg) {
     if (rows_per_seg <= 0) return WSI_EINVAL;
-    g_stem_fused = fused ? 1 : 0; g_stem_rows = rows_per_seg;
+    g_stem_fused = fused ? 1 : 0; g_stem_rows = rows_per_seg; g_stem_u8x = fused != 2;
     return WSI_OK;
 }
 
 int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
                                      int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                                     const void* stem_wpk, const float* stem_bias, int n, int h, int w,
+                                     const void* stem_wpk, const float* stem_bias, const void* stem_wpk_u8,
+                                     const float* stem_bias_u8, const float* norm_mean_std, int n, int h, int w,
                                      float* scratch, void* out_pf, int planes, void* stream) {
     if (!stem_wpk || !stem_bias || !scratch || !out_pf || n <= 0 || h % 16 || w % 4) return WSI_EINVAL;
     if (!in_f32 && (!slide || !tile_xy || !lut)) return WSI_EINVAL;
@@ -232,6 +276,15 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
     a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
     a.origins = tile_xy; a.lut = lut; a.wpk = stem_wpk; a.bias = stem_bias; a.out = scratch;
     a.N = n; a.H = h; a.W = w;
+    a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
+    for (int c = 0; c < 3; ++c) { a.offs[c] = 0.f; a.padv[c] = 0.f; }
+    if (stem_wpk_u8 && stem_bias_u8 && norm_mean_std && !in_f32 && g_stem_u8x) {      // host pointer: mean[3], std[3]
+        a.wpk_u8 = stem_wpk_u8; a.bias_u8 = stem_bias_u8;
+        for (int c = 0; c < 3; ++c) {
+            a.offs[c] = (float)lrintf(255.0f * norm_mean_std[c]);
+            a.padv[c] = (float)(255.0 * (double)norm_mean_std[c] - (double)a.offs[c]);
+        }
+    }
     if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
@@ -467,6 +520,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             const int pi_ = prof_open(st, 4, 2.0 * nn * (h / 2) * (w / 2) * 64.0 * 147.0);
             rc = wsi_stem_conv7x7_bn_relu_maxpool(in_f32 ? in_f32 + (size_t)n0 * 3 * h * w : nullptr, slide, pitch, slide_h,
                                                   slide_w, tile_xy ? tile_xy + 2 * n0 : nullptr, lut, wt->stem_w, wt->stem_b,
+                                                  wt->stem_w_u8, wt->stem_b_u8, wt->norm,
                                                   nn, h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0] + img_off(0, n0),
                                                   planes, st);
             prof_close(st, pi_);

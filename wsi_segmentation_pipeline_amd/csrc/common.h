@@ -160,4 +160,10 @@ struct StemArgs {
     const float* bias;         // 64
     float* out;                // [N][H/2][W/2][64] f32 (post ReLU)
     int N, H, W;               // patch size
+    // exact-u8 path of the fused kernel (mode 1, split precision): the pixel operand is the INTEGER x - offs[c]
+    // (exact in fp16), the normalisation 1/(255 std) is folded into fp16 hi/lo weights (x 2^8), the mean into the bias
+    const void* wpk_u8;        // [nt 2][s 14][plane 2][lane 64][8] fp16, or null: LUT path
+    const float* bias_u8;      // 64
+    float offs[3];             // round(255 mean[c])
+    float padv[3];             // 255 mean[c] - offs[c]: the value of a zero-padding pixel in this domain
 };

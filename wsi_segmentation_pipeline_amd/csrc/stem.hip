@@ -187,8 +187,10 @@ constexpr int SP_COLS = 68;                  // input columns per strip (2*31 + 
 constexpr int SP_RING = 16;                  // ring rows
 constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
 
-// PLANES = arithmetic of the stem itself (1: bf16, 2: bf16 hi/lo 3-pass); OUT = output line format (1, 2 or 3)
-template <int PLANES, int OUT>
+// PLANES = arithmetic of the stem itself (1: bf16, 2: bf16 hi/lo 3-pass); OUT = output line format (1, 2 or 3).
+// U8X (PLANES == 2, u8 slide input): the pixel operand is the exact integer x - round(255 mean) in ONE fp16 plane and
+// the weights carry the normalisation (fp16 hi/lo, x 2^8): two MFMA passes, result exact to ~2^-22 of the weights.
+template <int PLANES, int OUT, bool U8X = false>
 __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const StemArgs& a = A.s;
@@ -214,39 +216,58 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     for (int ks = 0; ks < 14; ++ks)
 #pragma unroll
         for (int p = 0; p < PLANES; ++p)
-            wreg[ks][p] = *((const bf16x8*)a.wpk + ((size_t)(wave * 14 + ks) * PLANES + p) * 64 + lane);
+            wreg[ks][p] = *((const bf16x8*)(U8X ? a.wpk_u8 : a.wpk) + ((size_t)(wave * 14 + ks) * PLANES + p) * 64 + lane);
     float bias[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = a.bias[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
+    for (int r = 0; r < 16; ++r) bias[r] = (U8X ? a.bias_u8 : a.bias)[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
+    const size_t slide_bytes = (size_t)a.SH * (size_t)a.slide_pitch;
 
     auto stage_rows = [&](int row_lo, int nrows) {                      // input rows [row_lo, row_lo+nrows) -> ring
         for (int i = tid; i < nrows * SP_COLS; i += 128) {
             const int r = i / SP_COLS, cc = i - r * SP_COLS;
             const int iy = row_lo + r, ix = ix0 + cc;
-            float v[3] = {0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                if (a.mode == 0) {
-                    const size_t base = ((size_t)n * 3 * a.H + iy) * a.W + ix;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = a.in_f32[base + (size_t)c * a.H * a.W];
-                } else {
+            const int slot = (iy + 64) & (SP_RING - 1);
+            const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            if constexpr (U8X) {
+                f16x4 xv = {(_Float16)a.padv[0], (_Float16)a.padv[1], (_Float16)a.padv[2], (_Float16)0.f};
+                if (inside) {
                     const int sx = tx + ix, sy = ty + iy;
-                    uint8_t px[3] = {0, 0, 0};
+                    unsigned rgb = 0u;                                  // outside the slide OpenSlide pads with black
                     if (sx >= 0 && sx < a.SW && sy >= 0 && sy < a.SH) {
-                        const uint8_t* pp = a.slide + (size_t)sy * a.slide_pitch + (size_t)sx * 3;
-                        px[0] = pp[0]; px[1] = pp[1]; px[2] = pp[2];
+                        const size_t off = (size_t)sy * a.slide_pitch + (size_t)sx * 3;
+                        const uint8_t* pp = a.slide + off;
+                        if (off + 4 <= slide_bytes) __builtin_memcpy(&rgb, pp, 4);   // one (unaligned) dword: R, G, B, next R
+                        else rgb = pp[0] | (pp[1] << 8) | (pp[2] << 16);             // last pixel of the buffer
                     }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = a.lut[c * 256 + px[c]];
+                    for (int c = 0; c < 3; ++c) xv[c] = (_Float16)((float)((rgb >> (8 * c)) & 255u) - a.offs[c]);   // exact
                 }
-            }
-            bf16x4 hi, lo;
+                *(f16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = xv;
+            } else {
+                float v[3] = {0.f, 0.f, 0.f};
+                if (inside) {
+                    if (a.mode == 0) {
+                        const size_t base = ((size_t)n * 3 * a.H + iy) * a.W + ix;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { hi[c] = (__bf16)v[c]; lo[c] = (__bf16)(v[c] - (float)hi[c]); }
-            hi[3] = (__bf16)0.f; lo[3] = (__bf16)0.f;
-            const int slot = (iy + 64) & (SP_RING - 1);
-            *(bf16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = hi;
-            if constexpr (PLANES == 2) *(bf16x4*)(smem + SP_PLANE + (size_t)(slot * SP_COLS + cc) * 8) = lo;
+                        for (int c = 0; c < 3; ++c) v[c] = a.in_f32[base + (size_t)c * a.H * a.W];
+                    } else {
+                        const int sx = tx + ix, sy = ty + iy;
+                        uint8_t px[3] = {0, 0, 0};
+                        if (sx >= 0 && sx < a.SW && sy >= 0 && sy < a.SH) {
+                            const uint8_t* pp = a.slide + (size_t)sy * a.slide_pitch + (size_t)sx * 3;
+                            px[0] = pp[0]; px[1] = pp[1]; px[2] = pp[2];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v[c] = a.lut[c * 256 + px[c]];
+                    }
+                }
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { hi[c] = (__bf16)v[c]; lo[c] = (__bf16)(v[c] - (float)hi[c]); }
+                hi[3] = (__bf16)0.f; lo[3] = (__bf16)0.f;
+                *(bf16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = hi;
+                if constexpr (PLANES == 2) *(bf16x4*)(smem + SP_PLANE + (size_t)(slot * SP_COLS + cc) * 8) = lo;
+            }
         }
     };
 
@@ -276,6 +297,11 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                 const int slot = (4 * py + 2 * mt - 3 + kh + 64) & (SP_RING - 1);
                 const char* xp = smem + (size_t)(slot * SP_COLS + 2 * lc + kw0) * 8;
                 const bf16x8 x0 = *(const bf16x8*)xp;
+                if constexpr (U8X) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[ks][1]), __builtin_bit_cast(f16x8, x0), acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[ks][0]), __builtin_bit_cast(f16x8, x0), acc[mt], 0, 0, 0);
+                    continue;
+                }
                 if constexpr (PLANES == 2) {
                     const bf16x8 x1 = *(const bf16x8*)(xp + SP_PLANE);
                     acc[mt] = mfma_bf16(wreg[ks][1], x0, acc[mt]);
@@ -289,8 +315,9 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float a0 = (col_ok && r0_ok) ? fmaxf(acc[0][r] + bias[r], 0.f) : 0.f;
-            const float a1 = (col_ok && r1_ok) ? fmaxf(acc[1][r] + bias[r], 0.f) : 0.f;
+            constexpr float ASC = U8X ? 1.0f / 256.0f : 1.0f;          // undo the 2^8 weight scale (exact)
+            const float a0 = (col_ok && r0_ok) ? fmaxf(acc[0][r] * ASC + bias[r], 0.f) : 0.f;
+            const float a1 = (col_ok && r1_ok) ? fmaxf(acc[1][r] * ASC + bias[r], 0.f) : 0.f;
             v[r] = fmaxf(fmaxf(carry[r], a0), a1);
             carry[r] = a1;
         }
@@ -359,8 +386,13 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
     const int Hp = a.H / 4, Wp = a.W / 4;
     const long long grid = (long long)a.N * ((Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
-    const size_t lds = (size_t)(planes == 1 ? 1 : 2) * SP_PLANE;
-    if (planes == 3)                                  // stem arithmetic stays bf16 hi/lo (its weights are packed that way)
+    const bool u8x = a.mode == 1 && a.wpk_u8 && a.bias_u8 && planes >= 2;
+    const size_t lds = (size_t)(planes == 1 || u8x ? 1 : 2) * SP_PLANE;
+    if (u8x && planes == 3)
+        hipLaunchKernelGGL((stem_pool_kernel<2, 3, true>), dim3((int)grid), dim3(128), lds, st, A);
+    else if (u8x)
+        hipLaunchKernelGGL((stem_pool_kernel<2, 2, true>), dim3((int)grid), dim3(128), lds, st, A);
+    else if (planes == 3)                             // f32 input: bf16 hi/lo arithmetic, mode-3 output lines
         hipLaunchKernelGGL((stem_pool_kernel<2, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (planes == 2)
         hipLaunchKernelGGL((stem_pool_kernel<2, 2>), dim3((int)grid), dim3(128), lds, st, A);

@@ -89,6 +89,17 @@ class TrunkEngine:
                                                planes, _np_ptr(pk), _np_ptr(bias)), 'wsi_prepack_stem')
         self.wt.stem_w = dev(pk).data_ptr()
         self.wt.stem_b = dev(bias).data_ptr()
+        if planes >= 2:                          # u8 slide input: transform folded into the weights (exact integer pixels)
+            pk8 = np.empty(self.lib.wsi_prepack_stem_bytes(2), np.uint8)
+            bias8 = np.empty(64, np.float32)
+            mean_a, std_a = np.asarray(mean, np.float32), np.asarray(std, np.float32)
+            native.check(self.lib.wsi_prepack_stem_u8(_np_ptr(w), _np_ptr(g), _np_ptr(b), _np_ptr(m), _np_ptr(v), BN_EPS,
+                                                      _np_ptr(mean_a), _np_ptr(std_a), planes, _np_ptr(pk8), _np_ptr(bias8)),
+                         'wsi_prepack_stem_u8')
+            self.wt.stem_w_u8 = dev(pk8).data_ptr()
+            self.wt.stem_b_u8 = dev(bias8).data_ptr()
+            for i in range(3):
+                self.wt.norm[i], self.wt.norm[3 + i] = float(mean_a[i]), float(std_a[i])
 
         def conv(wkey, bnkey, k):
             w = _f32(sd, wkey)

@@ -21,6 +21,7 @@ class NativeLibraryMissing(RuntimeError):
 class WsiTrunkWeights(C.Structure):
     _fields_ = [
         ('stem_w', C.c_void_p), ('stem_b', C.c_void_p),
+        ('stem_w_u8', C.c_void_p), ('stem_b_u8', C.c_void_p), ('norm', C.c_float * 6),
         ('conv_w', C.c_void_p * 16), ('conv_b', C.c_void_p * 16),
         ('down_w', C.c_void_p * 3), ('down_b', C.c_void_p * 3),
         ('head_w', C.c_void_p), ('head_b', C.c_void_p), ('head_k', C.c_int),
@@ -38,8 +39,9 @@ SIGNATURES = {
     'wsi_prepack_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     'wsi_prepack_stem_bytes': (_sz, [_i]),
     'wsi_prepack_stem': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
+    'wsi_prepack_stem_u8': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp]),
     'wsi_normalize_u8_lut': (_i, [_vp, _vp, _vp]),
-    'wsi_stem_conv7x7_bn_relu_maxpool': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'wsi_stem_conv7x7_bn_relu_maxpool': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'wsi_stem_set_mode': (_i, [_i, _i]),
     'wsi_conv3x3_bn_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_conv3x3_bn_act_cfg': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
