@@ -1,3 +1,3 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/test_gpu_trunk.py -x -q -m gpu -s -k "u8_slide or golden or edge or unfused" 2>&1 | grep -v "^$" | tail -14
+for r in 32 64 16; do echo "stem rows $r"; timeout -k 10 200 python tools/launch_times.py --planes 3 --stem-rows $r | grep "stem\|sum"; done

@@ -21,12 +21,15 @@ def main():
     ap.add_argument('--planes', type=int, default=3)
     ap.add_argument('--n', type=int, default=1000)
     ap.add_argument('--reps', type=int, default=5)
-    ap.add_argument('--s2', type=int, default=-1, help='wsi_conv_set_mode value (0 gather, 1 slab, 2 slab with 64-pixel tiles)')
+    ap.add_argument('--stem-rows', type=int, default=0, help='pooled rows per stem workgroup (default: library default)')
+    ap.add_argument('--s2', type=int, default=-1, help='wsi_conv_set_mode value (0 gather, 1 slab with 64-pixel tiles, 3 slab with 128-pixel tiles)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = native.load()
     if args.s2 >= 0:
         native.check(lib.wsi_conv_set_mode(args.s2), 'wsi_conv_set_mode')
+    if args.stem_rows:
+        native.check(lib.wsi_stem_set_mode(1, args.stem_rows), 'wsi_stem_set_mode')
     sd = W.make_resnet18_state_dict(11, with_fc=False)
     cls = W.make_head_state_dict(22, 'classifier')
     eng = TrunkEngine(sd, dev, planes=args.planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.n)

@@ -930,7 +930,7 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-int g_s2_small_tiles = 0;
+int g_s2_small_tiles = 1;                                // r01: 64-pixel tiles measured ~10 % faster (3 workgroups per CU)
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
 int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
     if (a.gi.C % 64 || a.go.C % 128 || planes < 1 || planes > 3) return WSI_EINVAL;

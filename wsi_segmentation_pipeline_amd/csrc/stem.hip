@@ -271,6 +271,46 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
         }
     };
 
+    // U8X: the 4 rows of the NEXT step are fetched into registers before this step's MFMAs (their latency hides
+    // behind them) and converted / written to the ring after the MFMAs, just before the step's barrier.
+    constexpr int NPF = (4 * SP_COLS + 127) / 128;                      // pixels per thread per step
+    unsigned pf_rgb[NPF];
+    auto fetch_rows = [&](int row_lo) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * 128;
+            const int r = i / SP_COLS, cc = i - r * SP_COLS;
+            const int iy = row_lo + r, ix = ix0 + cc;
+            unsigned rgb = 0u;
+            if (i < 4 * SP_COLS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                const int sx = tx + ix, sy = ty + iy;
+                if (sx >= 0 && sx < a.SW && sy >= 0 && sy < a.SH) {
+                    const size_t off = (size_t)sy * a.slide_pitch + (size_t)sx * 3;
+                    const uint8_t* pp = a.slide + off;
+                    if (off + 4 <= slide_bytes) __builtin_memcpy(&rgb, pp, 4);
+                    else rgb = pp[0] | (pp[1] << 8) | (pp[2] << 16);
+                }
+            }
+            pf_rgb[k] = rgb;
+        }
+    };
+    auto commit_rows = [&](int row_lo) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * 128;
+            if (i >= 4 * SP_COLS) continue;
+            const int r = i / SP_COLS, cc = i - r * SP_COLS;
+            const int iy = row_lo + r, ix = ix0 + cc;
+            const int slot = (iy + 64) & (SP_RING - 1);
+            f16x4 xv = {(_Float16)a.padv[0], (_Float16)a.padv[1], (_Float16)a.padv[2], (_Float16)0.f};
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xv[c] = (_Float16)((float)((pf_rgb[k] >> (8 * c)) & 255u) - a.offs[c]);
+            }
+            *(f16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = xv;
+        }
+    };
+
     // the first step is py0-1: it only produces the carried conv row 2*py0-1 (all zero for py0 == 0)
     stage_rows(4 * (py0 - 1) - 3, 9);
     __syncthreads();
@@ -283,7 +323,11 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     PFGeom go = pf_geom(a.N, Hp, Wp, 64);
 
     for (int py = py0 - 1; py < py1; ++py) {
-        if (py + 1 < py1) stage_rows(4 * (py + 1) + 2, 4);             // rows the NEXT step adds (not read by this step)
+        if constexpr (U8X) {
+            if (py + 1 < py1) fetch_rows(4 * (py + 1) + 2);            // rows the NEXT step adds: loads in flight
+        } else {
+            if (py + 1 < py1) stage_rows(4 * (py + 1) + 2, 4);         // rows the NEXT step adds (not read by this step)
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -374,6 +418,9 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                     }
                 }
             }
+        }
+        if constexpr (U8X) {
+            if (py + 1 < py1) commit_rows(4 * (py + 1) + 2);           // not read by this step: safe before the barrier
         }
         __syncthreads();                                                // next rows staged, this step's reads done
     }
