@@ -44,7 +44,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default='parity',
+    ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default='mx',
                     help='parity: bf16x2 split, 3 MFMA passes (logit error 3e-5); mx: fp16 pass + MX-fp4 cross terms '
                          '(5e-4, inside the 1e-3 contract); speed: single-pass bf16 (2e-2, outside the contract)')
     ap.add_argument('--batch', type=int, default=1000)
@@ -148,8 +148,8 @@ def main():
         if 'conv3x3_s1' in per_kind:
             ach = per_kind['conv3x3_s1']['tflops']
             traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if os.path.exists(tpath) and planes == 2:
+            tpath = os.path.join(ROOT, 'profiles', {2: 'r01_traffic.json', 3: 'r01_traffic_mx.json'}.get(planes, 'none'))
+            if os.path.exists(tpath):
                 # HBM bytes per launch from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE,
                 # collected at batch 1000); scaled to this run's batch
                 tj = json.load(open(tpath))
@@ -157,7 +157,7 @@ def main():
             roofline = {'kernel': 'conv3x3s1_slab3_kernel (13 launches per batch: the stride-1 3x3 convs of layer1-4)',
                         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                        'traffic_unit': 'HBM bytes per launch (PMC, profiles/r01_traffic.json)',
+                        'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)' % os.path.basename(tpath),
                         'avg_launch_ms': round(per_kind['conv3x3_s1']['avg_ms'], 4),
                         'mfma_passes': {2: '6 bf16 K=16 per 32-channel step', 3: '2 fp16 K=16 + 1 MX-fp4 K=64 per 32-channel step',
                                         1: '2 bf16 K=16 per 32-channel step'}[planes]}
