@@ -52,7 +52,7 @@ class ResNet(nn.Module):
     """forward(xs: (B,P,3,H,W)) -> (per-patch logits (P*B,4) patch-major, ensemble logits (B,4))."""
 
     def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
-                 norm_layer=None, precision='parity'):
+                 norm_layer=None, precision='mx'):
         super().__init__()
         if block is not BasicBlock or list(layers) != [2, 2, 2, 2]:
             raise NotImplementedError('the HIP path implements the ResNet-18 configuration used by resnet18()')

@@ -994,6 +994,8 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(20, 4, 1, 4, 2, false) \
     X(21, 4, 2, 2, 2, false) \
     X(25, 2, 2, 4, 3, false) \
+    X(27, 4, 4, 2, 1, false) \
+    X(39, 4, 4, 2, 1, true) \
     X(26, 4, 1, 2, 3, false) \
     X(30, 4, 1, 4, 2, true) \
     X(31, 4, 2, 2, 2, true) \

@@ -53,7 +53,7 @@ class TrunkEngine:
     state_dict: reference key names (conv1.weight, bn1.*, layerL.B.convK.weight, ...).
     """
 
-    def __init__(self, state_dict, device, planes=PARITY, head=None, max_batch=256,
+    def __init__(self, state_dict, device, planes=MX, head=None, max_batch=256,
                  mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), streams=1):
         self.lib = native.load()
         self.device = torch.device(device)
