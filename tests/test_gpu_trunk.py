@@ -145,23 +145,25 @@ def test_golden_tile_logits_256(dev, sd, golden_dir):
     assert err <= LOGIT_TOL and ferr <= 1e-3
 
 
+@pytest.mark.parametrize('planes', [2, 3])
 @pytest.mark.parametrize('shape', [(1, 32, 32), (1, 64, 64), (3, 96, 160), (2, 160, 64), (1, 512, 512), (5, 256, 256)])
-def test_edge_patch_shapes_vs_oracle(dev, sd, shape):
+def test_edge_patch_shapes_vs_oracle(dev, sd, shape, planes):
     """Smallest / non-square / large patches and ragged batch sizes through every stage (the 1x1 maps of
     32x32 patches, the gather fallback of 512x512 ones) against the CPU oracle."""
     from wsi_segmentation_pipeline_amd.engine import TrunkEngine
     n, h, w = shape
     u8 = W.make_u8_patches(100 + h + w, (n, 3, h, w))
     x = R.normalize_u8(u8)
-    eng = TrunkEngine(sd, dev, planes=2, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=4)
+    eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=4)
     feat, logits, fmap = eng.forward_f32(x.to(dev), feat=True, logits=True, fmap=True)
     with torch.no_grad():
         rf = R.trunk(sd, x)
         rfeat = torch.flatten(torch.nn.functional.adaptive_avg_pool2d(rf, 1), 1)
         rlog = torch.nn.functional.linear(rfeat, sd['fc0.weight'], sd['fc0.bias'])
     assert fmap.shape == rf.shape
-    assert float((fmap.cpu() - rf).abs().max() / rf.abs().max()) <= 2e-4
-    assert float((feat.cpu() - rfeat).abs().max()) <= 1e-3
+    assert float((fmap.cpu() - rf).abs().max() / rf.abs().max()) <= (2e-4 if planes == 2 else 1.5e-3)
+    # pooled features: absolute 1e-3 in the bf16x3 mode; relative to their scale in mode 3 (the contract is on the logits)
+    assert float((feat.cpu() - rfeat).abs().max()) <= (1e-3 if planes == 2 else 5e-4 * float(rfeat.abs().max()))
     assert float((logits.cpu() - rlog).abs().max()) <= LOGIT_TOL
 
 

@@ -343,8 +343,13 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     return rc;
 }
 
-extern int g_s2_small_tiles;
-int wsi_conv_set_mode(int s2_slab) { g_s2_slab = s2_slab ? 1 : 0; g_s2_small_tiles = s2_slab != 3; return WSI_OK; }
+extern int g_s2_small_tiles, g_xcd_order;
+int wsi_conv_set_mode(int s2_slab) {
+    g_xcd_order = (s2_slab & 8) ? 1 : 0;
+    s2_slab &= 7;
+    g_s2_slab = s2_slab ? 1 : 0; g_s2_small_tiles = s2_slab != 3;
+    return WSI_OK;
+}
 
 int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float* bias, int n, int h_in, int w_in,
                    int cin, int cout, int stride, int planes, void* stream) {

@@ -407,8 +407,17 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int nblocks = a.go.C / (WN * 32);
-    const int nb = blockIdx.x % nblocks;                      // b % 8 picks the XCD: one channel block per XCD for nblocks | 8
-    const int mtile = blockIdx.x / nblocks;
+    // Workgroup id -> (pixel tile, channel block).  Ids are dealt round-robin to the 8 XCDs (own L2 each): with
+    // bit 512 the channel blocks of one pixel tile get ids 8 apart, i.e. the SAME XCD, so the slab they share is
+    // fetched from HBM once instead of once per channel block.
+    int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    if (a.relu & 512) {
+        const int per = 8 * nblocks, r = blockIdx.x % per;
+        nb = r >> 3;
+        mtile = (blockIdx.x / per) * 8 + (r & 7);
+        const int mtiles = DENSE ? (a.gi.N * a.gi.H * a.gi.W + BM - 1) / BM : (a.gi.NS + BM - 1) / BM;
+        if (mtile >= mtiles) return;
+    }
     const int P = a.gi.P;
     const int ntile = nb * WN + wn;
     const int NC = (a.relu & 128) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // ablation: no main loop, epilogue only
@@ -549,7 +558,8 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : mtiles * nblocks;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
@@ -758,12 +768,12 @@ static int launch_stream(const ConvArgs& a, hipStream_t st) {
 // own weights into a second accumulator set (FUSE), so the block's two stride-2 convs cost one
 // pass over the input.  Ten taps are an even count: a 2-slot weight ring stays phase-aligned
 // across lines.
-template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE, int PMAX = 34>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
     constexpr int NTHREADS = WM * WN * 64;
-    constexpr int KMAX = ((4 * BM + 2 * 34 + 2) * 8 + NTHREADS - 1) / NTHREADS;      // pieces per thread, P <= 34
+    constexpr int KMAX = ((4 * BM + 2 * PMAX + 2) * 8 + NTHREADS - 1) / NTHREADS;    // pieces per thread, P <= PMAX
     constexpr int NT = FUSE ? 10 : 9;
     constexpr int RING = FUSE ? 2 : 3;                        // weight ring slots; NT % RING == 0 keeps lines aligned
     const int tid = threadIdx.x, lane = tid & 63;
@@ -771,8 +781,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int nblocks = a.go.C / (WN * 32);
-    const int nb = blockIdx.x % nblocks;
-    const int mtile = blockIdx.x / nblocks;
+    int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    if (a.relu & 512) {                                       // XCD-aware order, see conv3x3s1_slab3_kernel
+        const int per = 8 * nblocks, r = blockIdx.x % per;
+        nb = r >> 3;
+        mtile = (blockIdx.x / per) * 8 + (r & 7);
+        if (mtile >= (a.go.NS + BM - 1) / BM) return;
+    }
     const int P = a.go.P;
     const int q0 = a.go.G + mtile * BM;
     const int R01 = BM, R10 = 2 * BM + 1, R11 = 3 * BM + 1 + P;                      // region bases (pixels)
@@ -911,32 +926,41 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     }
 }
 
-template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE, int PMAX = 34>
 static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
-    if (a.go.C % (WN * 32) || a.go.P > 34) return WSI_EINVAL;
+    if (a.go.C % (WN * 32) || a.go.P > PMAX) return WSI_EINVAL;
     if ((unsigned long long)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * a.gi.C * PFmt<PLANES>::BPC >= 0xffffffffull) return WSI_EINVAL;
     const int mtiles = (a.go.NS + BM - 1) / BM;
     const int nblocks = a.go.C / (WN * 32);
     const int npieces = (4 * BM + 2 * a.go.P + 2) * 8;
     const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s2_slab_kernel<MT, WM, WN, PLANES, MINW, FUSE>;
+    auto k = conv3x3s2_slab_kernel<MT, WM, WN, PLANES, MINW, FUSE, PMAX>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : mtiles * nblocks;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+int g_xcd_order = 0;                                     // 1: ConvArgs.relu |= 512 for multi-channel-block launches
 int g_s2_small_tiles = 1;                                // r01: 64-pixel tiles measured ~10 % faster (3 workgroups per CU)
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
-int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st) {
+int wsi_s2_dispatch(const ConvArgs& a_in, int planes, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (g_xcd_order && a.go.C > 128) a.relu |= 512;
     if (a.gi.C % 64 || a.go.C % 128 || planes < 1 || planes > 3) return WSI_EINVAL;
     if (a.go.H * 2 != a.gi.H || a.go.W * 2 != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
     const bool fuse = a.out2 != nullptr;
     if (fuse && (!a.wpk2 || !a.bias2)) return WSI_EINVAL;
+    if (a.go.P > 34) {                                       // output maps wider than 33 (patches > 256): 64-pixel tiles, MINW 2
+        if (planes == 3) return fuse ? launch_s2slab<2, 1, 4, 3, 2, true, 130>(a, st) : launch_s2slab<2, 1, 4, 3, 2, false, 130>(a, st);
+        if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 2, true, 130>(a, st) : launch_s2slab<2, 1, 4, 2, 2, false, 130>(a, st);
+        return WSI_EINVAL;                                   // speed mode: gather kernel
+    }
     if (g_s2_small_tiles) {                                  // 64-pixel tiles: smaller slabs, more workgroups per CU
         if (planes == 3) return fuse ? launch_s2slab<2, 1, 4, 3, 3, true>(a, st) : launch_s2slab<2, 1, 4, 3, 3, false>(a, st);
         if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 3, true>(a, st) : launch_s2slab<2, 1, 4, 2, 3, false>(a, st);
@@ -1017,7 +1041,9 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(45, 2, 2, 4, 3) \
     X(46, 4, 1, 2, 3)
 
-int wsi_slab_dispatch_cfg(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
+int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (g_xcd_order && cfg >= 20 && cfg < 40 && !(a.relu & ~3)) a.relu |= 512;     // slab3 family only
     if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 / stream families implement mode 3
     if (cfg >= 50 && cfg <= 53 && planes == 3) {             // ablation builds of cfg 30 (bottleneck studies only)
         switch (cfg) {
