@@ -91,7 +91,8 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
                            void* stream);
 /* A-B hook: s2_slab = 1 (default) routes stride-2 3x3 convs to the phase-slab kernel (64-pixel tiles) and lets
  * the trunk fuse the downsample branch; 3 = the same with 128-pixel tiles; 0 = per-tap gather kernel + separate
- * 1x1 launch.  Process-wide. */
+ * 1x1 launch.  Flags added to the value: +8 XCD-aware workgroup order, +16 / +32 use the wide stride-1 kernel only
+ * from 256 channels / never (default: from 128).  Process-wide. */
 int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */

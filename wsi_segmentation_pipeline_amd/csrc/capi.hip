@@ -343,9 +343,10 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     return rc;
 }
 
-extern int g_s2_small_tiles, g_xcd_order;
+extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c;
 int wsi_conv_set_mode(int s2_slab) {
     g_xcd_order = (s2_slab & 8) ? 1 : 0;
+    g_wide_min_c = (s2_slab & 16) ? 256 : (s2_slab & 32) ? (1 << 30) : 128;      // +16: wide kernel from 256 channels, +32: never
     s2_slab &= 7;
     g_s2_slab = s2_slab ? 1 : 0; g_s2_small_tiles = s2_slab != 3;
     return WSI_OK;

@@ -718,6 +718,385 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(Con
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
+// 128 accumulator registers), so a pixel-fragment set read from LDS feeds SIX MFMAs instead of three and the
+// operand-load instructions per MFMA drop from 1.67 to 1.0 (the r01 ablations showed the slab3 loop is bound by
+// issuing and waiting for operand loads, not by MFMA, LDS bandwidth or HBM).  Workgroup = 2 x 2 waves = 256 pixels x
+// 128 channels.  The weights of one (line, tap) for the workgroup's four channel tiles (16 KB) are staged ONCE per
+// workgroup by LDS-DMA, double-buffered, one barrier per tap; the two waves that share a channel half read them
+// from LDS, the two waves that share a pixel half read the same slab.  No VMEM load returns to registers in the
+// main loop, so vmcnt only ever tracks DMA.
+template <int PLANES, int MINW, int ABL = 0>
+__global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, NT = 2, BM = 256, NTHREADS = 256;
+    constexpr int NF = PLANES == 3 ? 3 : 4;                   // 16-byte fragments per operand set (+ scale dword in mode 3)
+    char* const wl = smem;                                    // 2 x 16 KB weight buffers
+    char* const xl = smem + 32768;                            // pixel slab
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / 128;
+    const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    const int P = a.gi.P;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
+    int xoff[MT], qs[MT];
+    bool valid[MT];
+    int slab0, npieces;
+    {
+        const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
+        auto pos = [&](int i) {
+            const int n = i / HW, rem = i - n * HW;
+            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
+            return a.gi.G + n * a.gi.S + y * P + x;
+        };
+        const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
+        slab0 = pos(i0) - P - 1;
+        npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            valid[mt] = i < R;
+            qs[mt] = pos(valid[mt] ? i : i1);
+            xoff[mt] = qs[mt] - slab0 - (P + 1);
+        }
+    }
+    const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
+    const char* wsrc = (const char*)a.wpk + (size_t)(nb * 4) * NC * 9 * 4096 + (size_t)tid * 16;
+    // weights of (line c, tap t) for the four channel tiles -> buffer wb: thread tid moves piece tid of each tile
+    auto wdma = [&](int c, int t, char* wb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            dma16(wsrc + ((size_t)(j * NC + c) * 9 + t) * 4096, wb + (j * 256 + wave * 64) * 16);
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+
+    auto xload = [&](bf16x8(&x)[4], int Pl) {
+        const int base = lds_xbase(Pl, h);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
+        if constexpr (PLANES == 3) x[3] = lds_xscale(xl, base, Pl);
+    };
+    auto wread = [&](bf16x8(&w)[4], const char* wb, int nt) {
+        const char* src = wb + (wn * 2 + nt) * 4096 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) w[f] = *(const bf16x8*)(src + f * 1024);
+        if constexpr (PLANES == 3) w[3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + 3 * 1024), 0u, 0u, 0u});
+    };
+
+    int kpar = 0;                                             // weight buffer of the current tap
+    for (int c = 0; c < NC; ++c) {
+        if (c) __syncthreads();                               // slab and weight buffers are free again
+        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
+            const int i = i0 + lane;
+            const int Pl = i >> 3, sp = i & 7;
+            const int sl = sp ^ ((Pl >> 1) & 7);
+            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + sl * 16, xl + (size_t)i0 * 16);
+        }
+        wdma(c, 0, wl + kpar * 16384);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int Pc = P;
+        asm volatile("" : "+s"(Pc));
+        bf16x8 xf[2][4], wf[NT][4];
+        xload(xf[0], xoff[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const char* wb = wl + kpar * 16384;
+            if (t < 8) wdma(c, t + 1, wl + (kpar ^ 1) * 16384);
+            wread(wf[0], wb, 0);
+            wread(wf[1], wb, 1);
+            const int toff = (t / 3) * Pc + (t % 3);
+            const int toff_next = ((t + 1) / 3) * Pc + ((t + 1) % 3);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int k = t * MT + mt;
+                if constexpr (!(ABL & 32)) {
+                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
+                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                }
+                __builtin_amdgcn_sched_barrier(0);            // next pixel fragments requested before this tile's MFMAs
+                const bf16x8(&x)[4] = xf[k & 1];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8(&w)[4] = wf[nt];
+                    f32x16& d = acc[nt][mt];
+                    if constexpr (PLANES == 3) {
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
+                        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+                        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+                        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                                            __builtin_bit_cast(i32x4, x[3])[0]);
+                    } else if constexpr (PLANES == 2) {
+                        d = mfma_bf16(w[2], x[0], d);
+                        d = mfma_bf16(w[3], x[1], d);
+                        d = mfma_bf16(w[0], x[2], d);
+                        d = mfma_bf16(w[1], x[3], d);
+                        d = mfma_bf16(w[0], x[0], d);
+                        d = mfma_bf16(w[1], x[1], d);
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
+                    }
+                }
+            }
+            if (t < 8) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tap's weights have landed ...
+                __syncthreads();                                    // ... for everyone, and this tap's buffer is free
+            }
+            kpar ^= 1;
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = nb * 4 + wn * 2 + nt;
+        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
+        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// "Wide", fully asynchronous form: ONE workgroup per CU (one wave per SIMD, up to 512 registers each), every
+// global byte arrives by LDS-DMA and is double- (slab) or quadruple- (weights) buffered, so no MFMA ever waits on
+// HBM or L2: the slab of line c+1 is requested at the start of line c and only waited for at its end (a whole line
+// of MFMA time to land); the weights of tap g+3 are requested during tap g.  vmcnt completes in order per wave, so
+// the two kinds of DMA are issued by DIFFERENT waves (waves 0-1: slabs, waves 2-3: weights): the per-tap counted
+// wait of the weight waves never waits for a slab.  Weight fragments for tap g+1 are read from LDS into a second
+// register set while tap g multiplies.  One barrier per tap.
+template <int PLANES, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void conv3x3s1_wide2_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, NT = 2, BM = 256;
+    constexpr int NF = PLANES == 3 ? 3 : 4;
+    constexpr int WBUF = 16384, NWB = 4;
+    constexpr int XB = 45056;                                 // bytes per slab buffer (44 KB): a compile-time ds_read offset
+    char* const wl = smem;                                    // NWB x 16 KB weight ring
+    char* const xl0 = smem + NWB * WBUF;                      // two slab buffers of XB bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / 128;
+    const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    const int P = a.gi.P;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
+    const int NG = NC * 9;                                    // taps in K order (line-major)
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
+    int xoff[MT], qs[MT];
+    bool valid[MT];
+    int slab0, npieces;
+    {
+        const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
+        auto pos = [&](int i) {
+            const int n = i / HW, rem = i - n * HW;
+            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
+            return a.gi.G + n * a.gi.S + y * P + x;
+        };
+        const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
+        slab0 = pos(i0) - P - 1;
+        npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            valid[mt] = i < R;
+            qs[mt] = pos(valid[mt] ? i : i1);
+            xoff[mt] = qs[mt] - slab0 - (P + 1);
+        }
+    }
+    const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
+    // weight DMA (waves 2, 3): tap g of the K order = 4 channel tiles x 4 KB; the two waves move 128 pieces per tile.
+    // Buffer addressing: per-lane offset fixed, everything else scalar.
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)(nb * 4) * NG * 4096), 0, 4 * NG * 4096, 0x00020000);
+    const int wvoff = (tid & 127) * 16;
+    auto wdma = [&](int g) {
+        char* wb = wl + (g & (NWB - 1)) * WBUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+                dma16_buf(wrs, wb + j * 4096 + half * 2048 + (wave - 2) * 1024, wvoff, (j * NG + g) * 4096 + half * 2048);
+    };
+    // slab DMA (waves 0, 1): line c -> buffer c & 1
+    auto xdma = [&](int c) {
+        char* xb = xl0 + (size_t)(c & 1) * XB;
+        for (int i0 = wave * 64; i0 < npieces; i0 += 128) {
+            const int i = i0 + lane;
+            const int Pl = i >> 3, sp = i & 7;
+            const int sl = sp ^ ((Pl >> 1) & 7);
+            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + sl * 16, xb + (size_t)i0 * 16);
+        }
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+
+    auto wread = [&](bf16x8(&w)[NT][4], int g) {
+        const char* src = wl + (g & (NWB - 1)) * WBUF + (wn * 2) * 4096 + lane * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) w[nt][f] = *(const bf16x8*)(src + nt * 4096 + f * 1024);
+            if constexpr (PLANES == 3)
+                w[nt][3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + nt * 4096 + 3 * 1024), 0u, 0u, 0u});
+        }
+    };
+
+    // prologue: slab 0 and the first three taps' weights
+    if (wave < 2) xdma(0);
+    else { wdma(0); if (NG > 1) wdma(1); if (NG > 2) wdma(2); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 wf[2][NT][4], xf[2][4];
+    wread(wf[0], 0);
+
+    // LDS byte addresses of every (tile row, tap) pixel record and of its scale dword, relative to a slab buffer:
+    // loop-invariant, so the main loop spends no VALU on them beyond the two fragment XORs
+    int xaddr[MT][9], saddr[MT][9];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int Pl = xoff[mt] + (t / 3) * P + (t % 3);
+            xaddr[mt][t] = lds_xbase(Pl, h);
+            saddr[mt][t] = (xaddr[mt][t] ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1));
+        }
+    const char* const xlane = xl0;
+
+    for (int c2 = 0; c2 < NC; c2 += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                   // line parity = slab buffer: a compile-time offset
+            const int c = c2 + par;
+            auto xload = [&](bf16x8(&x)[4], int mt, int t) {
+                const int base = xaddr[mt][t];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) x[f] = *(const bf16x8*)(xlane + par * XB + (base ^ (f << 5)));
+                if constexpr (PLANES == 3)
+                    x[3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(xlane + par * XB + saddr[mt][t]), 0u, 0u, 0u});
+            };
+            if (!(ABL & 2) && wave < 2 && c + 1 < NC) xdma(c + 1);   // lands during this line's nine taps
+            xload(xf[0], 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int g = c * 9 + t;
+                constexpr int dummy = 0; (void)dummy;
+                if (!(ABL & 1) && wave >= 2 && g + 3 < NG) wdma(g + 3);
+                if (g + 1 < NG) wread(wf[(par * 9 + t + 1) & 1], g + 1);   // landed before the previous tap's barrier
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int k = t * MT + mt;
+                    if constexpr (!(ABL & 32)) {
+                        if (mt + 1 < MT) xload(xf[(k + 1) & 1], mt + 1, t);
+                        else if (t < 8) xload(xf[(k + 1) & 1], 0, t + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8(&x)[4] = xf[k & 1];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8(&w)[4] = wf[(par * 9 + t) & 1][nt];
+                        f32x16& d = acc[nt][mt];
+                        if constexpr (PLANES == 3) {
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
+                            const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+                            const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+                            d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                                                __builtin_bit_cast(i32x4, x[3])[0]);
+                        } else if constexpr (PLANES == 2) {
+                            d = mfma_bf16(w[2], x[0], d);
+                            d = mfma_bf16(w[3], x[1], d);
+                            d = mfma_bf16(w[0], x[2], d);
+                            d = mfma_bf16(w[1], x[3], d);
+                            d = mfma_bf16(w[0], x[0], d);
+                            d = mfma_bf16(w[1], x[1], d);
+                        } else {
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
+                        }
+                    }
+                }
+                // end of tap g: tap g+2's weights must be in LDS (read into registers during tap g+1); the weight
+                // waves leave only tap g+3's eight DMA instructions in flight.  At a line's last tap the slab waves
+                // wait for the next line's slab.
+                if (wave >= 2) {
+                    if (g + 3 < NG && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (t == 8) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if constexpr (!(ABL & 4)) __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = nb * 4 + wn * 2 + nt;
+        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
+        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
+    }
+}
+
+static long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
+    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+    const int mtiles = (int)((R + BM - 1) / BM);
+    const int HW = a.gi.H * a.gi.W;
+    auto pos = [&](long long i) { const long long n = i / HW, rem = i - n * HW; return (long long)a.gi.G + n * a.gi.S + (rem / a.gi.W) * a.gi.P + rem % a.gi.W; };
+    auto span = [&](int m) { const long long i0 = (long long)m * BM, i1 = (i0 + BM < R ? i0 + BM : R) - 1; return pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1; };
+    long long maxpix = span(mtiles - 1);
+    const int scan = mtiles < 4 * HW ? mtiles : 4 * HW;      // BM*HW pixels cover every phase of (tile start mod H*W)
+    for (int m = 0; m < scan; ++m) { const long long px = span(m); if (px > maxpix) maxpix = px; }
+    return maxpix;
+}
+
+template <int PLANES, int ABL = 0>
+static int launch_wide2(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 256, NTHREADS = 256, XB = 45056;
+    if (a.go.C % 128 || (a.gi.C / PFmt<PLANES>::CPL) % 2) return WSI_EINVAL;
+    const int nblocks = a.go.C / 128;
+    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+    const int mtiles = (int)((R + BM - 1) / BM);
+    const size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + 127) / 128 * 128) * 16;   // two waves stage the slab
+    if (xbytes > XB) return WSI_EINVAL;
+    const size_t lds = 4 * 16384 + 2 * XB;
+    auto k = conv3x3s1_wide2_kernel<PLANES, ABL>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+template <int PLANES, int MINW, int ABL = 0>
+static int launch_wide(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 256, NTHREADS = 256;
+    if (a.go.C % 128) return WSI_EINVAL;
+    const int nblocks = a.go.C / 128;
+    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+    const int mtiles = (int)((R + BM - 1) / BM);
+    const size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    const size_t lds = 32768 + xbytes;
+    if (lds > 160 * 1024) return WSI_EINVAL;
+    auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return WSI_EINVAL;
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
 static int g_num_cus = 0;
 template <int MT, int WM, int WN, int PLANES, int MINW>
 static int launch_stream(const ConvArgs& a, hipStream_t st) {
@@ -1044,7 +1423,19 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
 int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !(a.relu & ~3)) a.relu |= 512;     // slab3 family only
+    if (planes == 3 && cfg < 20) return WSI_EINVAL;
     if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 / stream families implement mode 3
+    if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
+    if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
+    if (cfg == 62) return planes == 3 ? launch_wide2<3>(a, st) : planes == 2 ? launch_wide2<2>(a, st) : launch_wide2<1>(a, st);
+    if (planes == 3 && cfg >= 63 && cfg <= 66) {             // ablations of cfg 62: no weight DMA / no slab DMA / neither / neither + no barriers
+        switch (cfg) {
+        case 63: return launch_wide2<3, 1>(a, st);
+        case 64: return launch_wide2<3, 2>(a, st);
+        case 65: return launch_wide2<3, 3>(a, st);
+        case 66: return launch_wide2<3, 7>(a, st);
+        }
+    }
     if (cfg >= 50 && cfg <= 53 && planes == 3) {             // ablation builds of cfg 30 (bottleneck studies only)
         switch (cfg) {
         case 50: return launch_slab3<4, 1, 4, 3, 2, true, 16>(a, st);
@@ -1074,7 +1465,12 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
 }
 
 // default config per layer shape (tuned on MI355X, tools/tune_conv.py)
-static int slab_default_cfg(const ConvArgs& a) { return a.go.C % 128 == 0 ? 30 : 31; }   // r01 tune: profiles/r01_tune_conv*.log
+int g_wide_min_c = 128;                                  // channel count from which the wide kernel (cfg 60) is the default
+                                                         // (r01: 3-8 % faster than cfg 30 on layers 2-4; A/B via wsi_conv_set_mode)
+static int slab_default_cfg(const ConvArgs& a, int planes) {                          // r01 tune: profiles/r01_tune_conv*.log
+    if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
+    return a.go.C % 128 == 0 ? 30 : 31;
+}
 
 // Host dispatch.  cfg < 0 selects the tuned default.
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
@@ -1083,7 +1479,7 @@ int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     if (planes == 3 && !(a.ksize == 3 && a.stride == 1)) return WSI_EINVAL;      // mode 3: slab kernels only
     if (a.ksize == 3 && a.stride == 1) {
         if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;
-        return wsi_slab_dispatch_cfg(a, planes, cfg < 0 ? slab_default_cfg(a) : cfg, st);
+        return wsi_slab_dispatch_cfg(a, planes, cfg < 0 ? slab_default_cfg(a, planes) : cfg, st);
     }
     if ((a.ksize == 3 || a.ksize == 1) && (a.stride == 1 || a.stride == 2)) {
         if (a.go.H * a.stride != a.gi.H || a.go.W * a.stride != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
