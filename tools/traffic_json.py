@@ -23,7 +23,7 @@ for name, d in acc.items():
     write = 1024.0 * sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1)
     res[name] = {'launches': n, 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
                  'hbm_bytes_per_launch': fetch + write}
-slab = {k: v for k, v in res.items() if 'conv3x3s1_slab3' in k}
+slab = {k: v for k, v in res.items() if 'conv3x3s1_' in k}      # slab3 + wide: all stride-1 3x3 launches
 tot_l = sum(v['launches'] for v in slab.values())
 summary = {'bench_args': sys.argv[3:], 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 (gfx950), KiB units',
            'kernels': res,
