@@ -89,10 +89,23 @@ int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float
 int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf, const void* wpk3, const float* bias3,
                            const void* wpk1, const float* bias1, int n, int h_in, int w_in, int cin, int cout, int planes,
                            void* stream);
+/* Phase-split tensors: the four phase images (y&1, x&1) of an (n,h,w,c) tensor, each a PF tensor of geometry
+ * (n,h/2,w/2,c), concatenated (wsi_pf_split_bytes = 4 * wsi_pf_bytes(n,h/2,w/2,c,planes); zero-fill once like a PF
+ * buffer).  A stride-1 conv can WRITE its output in this form (wsi_conv3x3_bn_act_split; h, w even; planes >= 2) and
+ * the stride-2 block entry can READ it (wsi_conv3x3s2_ds_fused_split: the "wide" stride-2 kernel, 8 waves sharing
+ * one weight stage per tap; output maps up to 33 wide, cout % 128 == 0, planes >= 2, otherwise -EINVAL).  Used by
+ * wsi_trunk_forward between the residual stages; resnets_shift.py:41,173-177 as above. */
+size_t wsi_pf_split_bytes(int n, int h, int w, int c, int planes);
+int wsi_conv3x3_bn_act_split(const void* in_pf, void* out_split, const void* resid_pf, const void* wpk, const float* bias,
+                             int n, int h, int w, int cin, int cout, int relu, int planes, void* stream);
+int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* out_ds_pf, const void* wpk3,
+                                 const float* bias3, const void* wpk1, const float* bias1, int n, int h_in, int w_in,
+                                 int cin, int cout, int planes, void* stream);
 /* A-B hook: s2_slab = 1 (default) routes stride-2 3x3 convs to the phase-slab kernel (64-pixel tiles) and lets
  * the trunk fuse the downsample branch; 3 = the same with 128-pixel tiles; 0 = per-tap gather kernel + separate
  * 1x1 launch.  Flags added to the value: +8 XCD-aware workgroup order, +16 / +32 use the wide stride-1 kernel only
- * from 256 channels / never (default: from 128).  Process-wide. */
+ * from 256 channels / never (default: from 128), +128 the trunk keeps ordinary PF between stages (no phase-split
+ * hand-over to the wide stride-2 kernel).  Process-wide. */
 int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */

@@ -210,3 +210,50 @@ def test_fused_stride2_block_entry(dev, shape):
         else:
             real = E.pf_pack(torch.full_like(g3, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
             assert not bool((o3.view(torch.int16)[~real] != 0).any()) and not bool((o1.view(torch.int16)[~real] != 0).any())
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 128, 16, 16), (2, 64, 128, 64, 64), (3, 128, 256, 32, 32), (5, 256, 512, 16, 16), (7, 256, 512, 4, 4), (1, 64, 128, 2, 2)])
+def test_phase_split_stride2_block(dev, shape):
+    """Stride-1 conv writing its output phase-split (wsi_conv3x3_bn_act_split) feeding the wide stride-2 kernel
+    (wsi_conv3x3s2_ds_fused_split) == conv -> (stride-2 conv + ReLU, 1x1 stride-2 downsample) of the oracle."""
+    import ctypes as C
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    n, cin, cout, h, w = shape
+    lib = native.load()
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for planes, tol in ((2, 2 * TOL_PARITY), (3, 2 * TOL_MX)):
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(n, cin, h, w, generator=g).abs_()
+        w0 = torch.randn(cin, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        w3 = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        w1 = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+        mkbn = lambda c: (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+                          torch.rand(c, generator=g) + 0.5)
+        bn0, bn3, bn1 = mkbn(cin), mkbn(cout), mkbn(cout)
+        bnf = lambda t, b: F.batch_norm(t, b[2], b[3], b[0], b[1], False, 0.0, 1e-5)
+        mid = F.relu(bnf(F.conv2d(x, w0, None, 1, 1), bn0) + x)
+        ref3 = F.relu(bnf(F.conv2d(mid, w3, None, 2, 1), bn3))
+        ref1 = bnf(F.conv2d(mid, w1, None, 2, 0), bn1)
+        wp0, b0 = E.prepack_conv(w0, bn0, planes, dev)
+        wp3, b3 = E.prepack_conv(w3, bn3, planes, dev)
+        wp1, b1 = E.prepack_conv(w1, bn1, planes, dev)
+        xpf = E.pf_pack(x.to(dev), planes)
+        split = torch.zeros(lib.wsi_pf_split_bytes(n, h, w, cin, planes), dtype=torch.uint8, device=dev)
+        native.check(lib.wsi_conv3x3_bn_act_split(xpf.data_ptr(), split.data_ptr(), xpf.data_ptr(), wp0.data_ptr(), b0.data_ptr(),
+                                                  n, h, w, cin, cin, 1, planes, st()), 'conv split')
+        # the four phase images unpack to the four sub-sampled grids of the intermediate
+        per = lib.wsi_pf_bytes(n, h // 2, w // 2, cin, planes)
+        for ph in range(4):
+            img = E.pf_unpack(split[ph * per:(ph + 1) * per], n, cin, h // 2, w // 2, planes).cpu()
+            assert _rel_err(img, mid[:, :, (ph >> 1)::2, (ph & 1)::2]) <= tol
+        o3, o1 = E.pf_zeros(n, cout, h // 2, w // 2, planes, dev), E.pf_zeros(n, cout, h // 2, w // 2, planes, dev)
+        native.check(lib.wsi_conv3x3s2_ds_fused_split(split.data_ptr(), o3.data_ptr(), o1.data_ptr(), wp3.data_ptr(), b3.data_ptr(),
+                                                      wp1.data_ptr(), b1.data_ptr(), n, h, w, cin, cout, planes, st()), 'fused s2 split')
+        g3 = E.pf_unpack(o3, n, cout, h // 2, w // 2, planes).cpu()
+        g1 = E.pf_unpack(o1, n, cout, h // 2, w // 2, planes).cpu()
+        e3, e1 = _rel_err(g3, ref3), _rel_err(g1, ref1)
+        print('phase-split block', shape, 'planes', planes, 'rel err', e3, e1)
+        assert e3 <= tol and e1 <= tol
+        if planes == 3:
+            real = E.pf_pack(torch.ones_like(g3).to(dev), 3).view(-1, 128)[:, :64].ne(0).any(1)
+            assert not bool(o3.view(-1, 128)[~real].ne(0).any()) and not bool(o1.view(-1, 128)[~real].ne(0).any())

@@ -1,12 +1,4 @@
-set -e
 cd $GRAFT_REPO_ROOT
-bash tools/collect_traffic.sh r01e_mx --mode mx
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01e -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r01e_bench_under_rocprof.json 2> gpurun_out/prof_r01e.err
-cp gpurun_out/traffic_r01e_mx.json profiles/r01_traffic_mx.json
-timeout -k 10 400 python bench.py > gpurun_out/r01e_bench_mx.json 2> gpurun_out/r01e_bench_mx.err
-timeout -k 10 400 python bench.py --mode parity --no-cpu-baseline > gpurun_out/r01e_bench_parity.json 2> /dev/null
-timeout -k 10 400 python bench.py --mode speed --no-cpu-baseline > gpurun_out/r01e_bench_speed.json 2> /dev/null
-timeout -k 10 400 python bench.py --streams 2 --no-cpu-baseline > gpurun_out/r01e_bench_mx_streams2.json 2> /dev/null
-timeout -k 10 200 python tools/launch_times.py --planes 3 > gpurun_out/r01e_launch_times_mx.txt
-cp gpurun_out/prof_r01e/*/*_kernel_stats.csv gpurun_out/r01e_kernel_stats.csv
+timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+for m in 1 129 1 129; do echo "mode $m"; timeout -k 10 200 python tools/launch_times.py --planes 3 --s2 $m | grep "s2\|sum" | tr '\n' ' '; echo; done
+timeout -k 10 200 python tools/launch_times.py --planes 2 | tail -1

@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--ablate', type=str, default='1', help='comma list of relu/ablation bit masks')
     ap.add_argument('--noresid', action='store_true')
     ap.add_argument('--zero', action='store_true', help='all-zero activations (clock / power test)')
+    ap.add_argument('--wcopies', type=int, default=1, help='study: replicate the packed weights N times (<= 16), workgroups spread over the copies')
     ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
     args = ap.parse_args()
     lib = native.load()
@@ -41,16 +42,19 @@ def main():
             x.zero_()
         wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
         wpk, bias = E.prepack_conv(wt, None, args.planes, dev)
+        if args.wcopies > 1:
+            wpk = wpk.repeat(args.wcopies).contiguous()
         xpf = E.pf_pack(x.to(dev), args.planes)
         rpf = E.pf_pack(torch.randn(n, c, h, w, generator=g).to(dev), args.planes)
         outs = {cfg: E.pf_zeros(n, c, h, w, args.planes, dev) for cfg in range(NCFG)}
         flops = 2.0 * n * h * w * c * c * 9
 
         flag = [1]
+        wc = (args.wcopies - 1) << 10
 
         def run(cfg):
             return lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), outs[cfg].data_ptr(), None if args.noresid else rpf.data_ptr(),
-                                              wpk.data_ptr(), bias.data_ptr(), n, h, w, c, c, 1, flag[0], args.planes, cfg, st())
+                                              wpk.data_ptr(), bias.data_ptr(), n, h, w, c, c, 1, flag[0] | wc, args.planes, cfg, st())
         want = [int(v) for v in args.cfgs.split(',')] if args.cfgs else list(range(NCFG))
         valid = [cfg for cfg in want if run(cfg) == 0]
         torch.cuda.synchronize()

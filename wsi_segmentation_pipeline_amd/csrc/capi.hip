@@ -292,10 +292,11 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
 }
 
 static int g_s2_slab = 1;                             // stride-2 convs: phase-slab kernel (1) or per-tap gather kernel (0)
+static int g_s2_split = 1;                            // trunk: phase-split stage outputs + wide stride-2 kernel (A/B: wsi_conv_set_mode +128 off)
 
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
-                       int cfg = -1) {
+                       int cfg = -1, int split_out = 0) {
     if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
     if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
     ConvArgs a;
@@ -304,6 +305,9 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
     a.stride = stride; a.ksize = ksize; a.relu = relu;
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
+    a.in_split_pixels = 0;
+    a.out_split_pixels = split_out ? pf_alloc_pixels(n, h_in / 2, w_in / 2) : 0;
+    if (split_out && (stride != 1 || ksize != 3 || h_in % 2 || w_in % 2 || planes < 2)) return WSI_EINVAL;
     if (ksize == 3 && stride == 2 && cout % 128 == 0 && cfg != 0 && g_s2_slab) {
         const int rc = wsi_s2_dispatch(a, planes, (hipStream_t)stream);
         if (rc != WSI_EINVAL) return rc;               // EINVAL: shape outside the slab kernel's range -> gather kernel
@@ -315,6 +319,33 @@ int wsi_conv3x3_bn_act(const void* in_pf, void* out_pf, const void* resid_pf, co
                        int n, int h_in, int w_in, int cin, int cout, int stride, int relu, int planes,
                        void* stream) {
     return conv_common(in_pf, out_pf, resid_pf, wpk, bias, n, h_in, w_in, cin, cout, stride, 3, relu, planes, stream);
+}
+
+size_t wsi_pf_split_bytes(int n, int h, int w, int c, int planes) {
+    if (h % 2 || w % 2) return 0;
+    return 4 * wsi_pf_bytes(n, h / 2, w / 2, c, planes);
+}
+
+int wsi_conv3x3_bn_act_split(const void* in_pf, void* out_split, const void* resid_pf, const void* wpk, const float* bias,
+                             int n, int h, int w, int cin, int cout, int relu, int planes, void* stream) {
+    return conv_common(in_pf, out_split, resid_pf, wpk, bias, n, h, w, cin, cout, 1, 3, relu, planes, stream, -1, 1);
+}
+
+int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* out_ds_pf, const void* wpk3,
+                                 const float* bias3, const void* wpk1, const float* bias1, int n, int h_in, int w_in,
+                                 int cin, int cout, int planes, void* stream) {
+    if (!in_split || !out_conv_pf || !out_ds_pf || !wpk3 || !bias3 || !wpk1 || !bias1 || n <= 0 || h_in % 2 || w_in % 2)
+        return WSI_EINVAL;
+    if (in_split == out_conv_pf || in_split == out_ds_pf || out_conv_pf == out_ds_pf) return WSI_EINVAL;
+    ConvArgs a;
+    a.in = in_split; a.out = out_conv_pf; a.resid = nullptr; a.wpk = wpk3; a.bias = bias3;
+    a.gi = pf_geom(n, h_in, w_in, cin);
+    a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
+    a.stride = 2; a.ksize = 3; a.relu = 1;
+    a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
+    a.out_split_pixels = 0;
+    a.in_split_pixels = pf_alloc_pixels(n, h_in / 2, w_in / 2);
+    return wsi_s2_dispatch(a, planes, (hipStream_t)stream);      // EINVAL outside the wide kernel's range (output maps wider than 33)
 }
 
 int wsi_conv3x3_bn_act_cfg(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias,
@@ -335,6 +366,7 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
     a.stride = 2; a.ksize = 3; a.relu = 1;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
+    a.in_split_pixels = 0; a.out_split_pixels = 0;
     int rc = wsi_s2_dispatch(a, planes, (hipStream_t)stream);
     if (rc == WSI_EINVAL) {                             // e.g. maps wider than 33: two per-tap gather launches
         rc = conv_common(in_pf, out_conv_pf, nullptr, wpk3, bias3, n, h_in, w_in, cin, cout, 2, 3, 1, planes, stream, 0);
@@ -343,8 +375,10 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     return rc;
 }
 
-extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c;
+extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate;
 int wsi_conv_set_mode(int s2_slab) {
+    g_s2_split = (s2_slab & 128) ? 0 : 1;
+    g_s2_ablate = (s2_slab & 64) ? 1 : 0;                 // bottleneck study only: stride-2 kernel without weight loads (wrong results)
     g_xcd_order = (s2_slab & 8) ? 1 : 0;
     g_wide_min_c = (s2_slab & 16) ? 256 : (s2_slab & 32) ? (1 << 30) : 128;      // +16: wide kernel from 256 channels, +32: never
     s2_slab &= 7;
@@ -458,7 +492,7 @@ int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk) {
 }
 struct TrunkPlan {
     size_t stem_scratch;          // byte offsets into the workspace
-    size_t buf[4][3];
+    size_t buf[4][4];             // [stage][0..2]: rotating PF buffers; [stage][3]: phase-split output of the stage (stages 0-2)
     size_t total;
     int sh[4], sw[4], sc[4];
 };
@@ -474,6 +508,8 @@ static int trunk_plan(int n, int h, int w, int planes, TrunkPlan& p) {
             p.buf[s][b] = off;
             off += align_up(wsi_pf_bytes(n, p.sh[s], p.sw[s], p.sc[s], planes), 256);
         }
+        p.buf[s][3] = off;                             // never holds anything but the phase-split form: its pads stay zero
+        if (s < 3 && planes >= 2) off += align_up(wsi_pf_split_bytes(n, p.sh[s], p.sw[s], p.sc[s], planes), 256);
     }
     p.total = off;
     return WSI_OK;
@@ -518,6 +554,10 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     const int cs = g_chunk_stem > 0 ? g_chunk_stem : n, c1 = g_chunk_l1 > 0 ? g_chunk_l1 : n;
     const int H1 = p.sh[0], W1 = p.sw[0];
     const int do_l1 = stop_after != 0;
+    // stage s writes its output phase-split when the next stage's entry can read it with the wide stride-2 kernel:
+    // full runs only (taps unpack ordinary PF), split precision, next output maps <= 33 wide, whole-batch stages
+    auto can_split = [&](int s) { return g_s2_split && g_s2_slab && stop_after >= 8 && planes >= 2 && s < 3 && p.sw[s + 1] <= 33; };
+    const bool split0 = can_split(0) && c1 >= n;
     int l1_out = 0;                                    // buffer index holding layer1's output
     for (int n1 = 0; n1 < n; n1 += c1) {
         const int nn1 = n - n1 < c1 ? n - n1 : c1;
@@ -540,8 +580,13 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                  *out = ws + p.buf[0][o] + img_off(0, n1);
             PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
                                                                      H1, W1, 64, 64, 1, 1, planes, st));
-            PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
-                                                                     nn1, H1, W1, 64, 64, 1, 1, planes, st));
+            if (b == 1 && split0) {                    // layer1's output feeds only the stride-2 entry of layer2
+                PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act_split(mid, ws + p.buf[0][3], x, wt->conv_w[3], wt->conv_b[3],
+                                                                               nn1, H1, W1, 64, 64, 1, planes, st));
+            } else {
+                PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
+                                                                         nn1, H1, W1, 64, 64, 1, 1, planes, st));
+            }
             cur = o;
         }
         l1_out = cur;
@@ -550,7 +595,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     if (stop_after >= 0 && stop_after <= 2) return WSI_OK;
 
     int cur = l1_out;
-    const void* x = ws + p.buf[0][cur];
+    const void* x = split0 ? ws + p.buf[0][3] : ws + p.buf[0][cur];
+    bool x_split = split0;
     int block = 2;
     for (int s = 1; s < 4; ++s) {
         const int H = p.sh[s], W = p.sw[s], C = p.sc[s];
@@ -564,8 +610,10 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 out = ws + p.buf[s][0];
                 if (g_s2_slab) {
                     const int pi_ = prof_open(st, 2, 2.0 * n * H * W * (double)C * (C / 2) * 10);
-                    rc = wsi_conv3x3s2_ds_fused(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1], wt->down_b[s - 1], n,
-                                                2 * H, 2 * W, C / 2, C, planes, st);
+                    rc = x_split ? wsi_conv3x3s2_ds_fused_split(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1],
+                                                                wt->down_b[s - 1], n, 2 * H, 2 * W, C / 2, C, planes, st)
+                                 : wsi_conv3x3s2_ds_fused(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1], wt->down_b[s - 1], n,
+                                                          2 * H, 2 * W, C / 2, C, planes, st);
                     prof_close(st, pi_);
                     if (rc) return rc;
                 } else {
@@ -587,8 +635,16 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 cur = o;
                 last_off = p.buf[s][o];
             }
-            PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C,
-                                                             C, 1, 1, planes, st));
+            if (b == 1 && can_split(s)) {              // the stage's output feeds only the next stage's stride-2 entry
+                out = ws + p.buf[s][3];
+                PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act_split(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W,
+                                                                         C, C, 1, planes, st));
+                x_split = true;
+            } else {
+                PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C,
+                                                                 C, 1, 1, planes, st));
+                x_split = false;
+            }
             x = out;
             ++block;
             last_stage = s;

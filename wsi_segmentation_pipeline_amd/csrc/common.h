@@ -90,7 +90,23 @@ struct ConvArgs {
     void* out2;            // PF activations shaped like out
     const void* wpk2;      // 1x1 weights [ntile][line][1][f][lane][8]
     const float* bias2;
+    // Phase-split tensors (the input layout of the stride-2 "wide" kernel): the four phase images (y&1, x&1) of an
+    // (N,H,W,C) tensor, each a PF tensor of geometry (N,H/2,W/2,C), concatenated `*_split_pixels` pixels apart.
+    // 0 = ordinary PF.  out_split_pixels: the epilogue writes `out` phase-split; in_split_pixels: `in` is phase-split.
+    long long out_split_pixels, in_split_pixels;
 };
+
+// byte offset of output position q (a real pixel of geometry g) in an ordinary or phase-split tensor
+static inline __device__ size_t pf_out_offset(const PFGeom& g, long long split_pixels, int q, size_t pixstride) {
+    if (!split_pixels) return (size_t)q * pixstride;
+    int r = q - g.G;
+    const int n = r / g.S;
+    r -= n * g.S;
+    const int y = r / g.P, x = r - y * g.P;
+    const int P2 = g.W / 2 + 1, S2 = (g.H / 2 + 1) * P2;
+    const long long q2 = (long long)(P2 + 1) + (long long)n * S2 + (y >> 1) * P2 + (x >> 1);
+    return (size_t)(((y & 1) * 2 + (x & 1)) * split_pixels + q2) * pixstride;
+}
 
 static inline __device__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

@@ -23,10 +23,12 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
     const int h = lane >> 5;
     const size_t pixstride = (size_t)a.go.C * PFmt<PLANES>::BPC;
     const size_t chan_off = (size_t)ntile * (32 * PFmt<PLANES>::BPC) + (size_t)(4 * h) * 2;
-    size_t poff[MT];
+    size_t poff[MT], ooff[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
         poff[mt] = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + chan_off;   // invalid rows read a real pixel, store nothing
+        ooff[mt] = a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, valid[mt] ? qs[mt] : a.go.G, pixstride) + chan_off : poff[mt];
+    }
 
     // phase 1: every residual load of the tile in flight at once (branch-free)
     bf16x4 rh[MT][4], rl[MT][4];
@@ -77,7 +79,7 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
                 lo[i] = (__bf16)(v[i] - (float)hi[i]);
             }
             if (valid[mt] && !(a.relu & 2)) {
-                char* op = (char*)a.out + poff[mt] + 16 * g;
+                char* op = (char*)a.out + ooff[mt] + 16 * g;
                 if (a.relu & 256) {
                     __builtin_nontemporal_store(hi, (bf16x4*)op);
                     if constexpr (PLANES == 2) __builtin_nontemporal_store(lo, (bf16x4*)(op + 64));
@@ -147,7 +149,7 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
         const unsigned s0 = __shfl_xor(h ? ql[0] : qh[0], 32), s1 = __shfl_xor(h ? ql[1] : qh[1], 32);
         const u32x4 q4 = h ? u32x4{s0, s1, qh[0], qh[1]} : u32x4{ql[0], ql[1], s0, s1};
         if (valid[mt] && !(a.relu & 2)) {
-            char* ol = (char*)a.out + loff;
+            char* ol = (char*)a.out + (a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, qs[mt], pixstride) + (size_t)ntile * 128 : loff);
             *(f16x8*)(ol + 32 * h) = hv[0];
             *(f16x8*)(ol + 32 * h + 16) = hv[1];
             *(u32x4*)(ol + 64 + 16 * h) = q4;
@@ -454,8 +456,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         }
     }
     const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
+    // study hook (tools/tune_conv.py --wcopies): bits 10-13 of relu = number of back-to-back copies of the packed
+    // weights minus one; workgroups spread over the copies (do hot weight lines serialise on few L2 channels?)
+    const size_t wcopy = (size_t)(mtile % (((a.relu >> 10) & 15) + 1)) * (size_t)(a.go.C / 32) * NC * 9 * 4096;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
+        (void*)((const char*)a.wpk + wcopy + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
     const int wvoff = lane * 16;
 
     f32x16 acc[MT];
@@ -1147,7 +1152,7 @@ static int launch_stream(const ConvArgs& a, hipStream_t st) {
 // own weights into a second accumulator set (FUSE), so the block's two stride-2 convs cost one
 // pass over the input.  Ten taps are an even count: a 2-slot weight ring stays phase-aligned
 // across lines.
-template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE, int PMAX = 34>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE, int PMAX = 34, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
@@ -1263,8 +1268,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             asm volatile("" ::: "memory");
-            if (t + 1 < NT) wload(wbuf[(t + 1) % RING], c, t + 1);
-            else if (c + 1 < NC) wload(wbuf[0], c + 1, 0);
+            if constexpr (!(ABL & 16)) {                      // ABL 16: bottleneck study, stale weight registers
+                if (t + 1 < NT) wload(wbuf[(t + 1) % RING], c, t + 1);
+                else if (c + 1 < NC) wload(wbuf[0], c + 1, 0);
+            }
             asm volatile("" ::: "memory");                    // pin the prefetch above this tap's MFMAs
             const int toff = tap_off(t, Pc);
             const int toff_next = t + 1 < NT ? tap_off(t + 1, Pc) : 0;
@@ -1305,7 +1312,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     }
 }
 
-template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE, int PMAX = 34>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool FUSE, int PMAX = 34, int ABL = 0>
 static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
     if (a.go.C % (WN * 32) || a.go.P > PMAX) return WSI_EINVAL;
@@ -1315,7 +1322,7 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     const int npieces = (4 * BM + 2 * a.go.P + 2) * 8;
     const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s2_slab_kernel<MT, WM, WN, PLANES, MINW, FUSE, PMAX>;
+    auto k = conv3x3s2_slab_kernel<MT, WM, WN, PLANES, MINW, FUSE, PMAX, ABL>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
@@ -1325,11 +1332,182 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+// one (pixel tile, channel tile, 32-channel line, tap) step of every precision mode
+template <int PLANES>
+static __device__ __forceinline__ void mfma_step(f32x16& d, const bf16x8 (&w)[4], const bf16x8 (&x)[4]) {
+    if constexpr (PLANES == 3) {
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
+        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                            __builtin_bit_cast(i32x4, x[3])[0]);
+    } else if constexpr (PLANES == 2) {
+        d = mfma_bf16(w[2], x[0], d);
+        d = mfma_bf16(w[3], x[1], d);
+        d = mfma_bf16(w[0], x[2], d);
+        d = mfma_bf16(w[1], x[3], d);
+        d = mfma_bf16(w[0], x[0], d);
+        d = mfma_bf16(w[1], x[1], d);
+    } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Stride-2 3x3 conv + fused 1x1 stride-2 downsample over a PHASE-SPLIT input (common.h ConvArgs): each of the four
+// input phase images is an ordinary PF tensor in the OUTPUT geometry, so the pixels a tile of 256 output positions
+// needs from one phase are ONE contiguous range (plain LDS-DMA, no gather) and the taps of that phase are LDS address
+// shifts.  The r01 ablation showed the phase-slab kernel spends 40-55 % of its time re-streaming weights (every wave
+// fetches 3.25 KB per tap for 64 pixels); here 8 waves = 4 pixel quarters x 2 channel halves share one 16 KB weight
+// stage per tap (LDS-DMA, double-buffered): 3.25x less weight traffic per pixel.  Work items per 32-channel line:
+// phase 00: tap (1,1) + the downsample tap; 01: (1,0) (1,2); 10: (0,1) (2,1); 11: (0,0) (0,2) (2,0) (2,2).  The
+// next item's pixels are fetched while the current one multiplies (two slab buffers); waves 0-3 issue the pixel
+// DMA, waves 4-7 the weight DMA, so each wave's in-order vmcnt tracks one kind only.  One barrier per tap.
+template <int PLANES>
+__global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 2, NT = 2, BM = 256;
+    constexpr int NF = PLANES == 3 ? 3 : 4;
+    constexpr int WBUF = 16384, XB = 40960;                   // X: (256 + 34 + 2) pixels rounded to whole 256-thread DMA rounds
+    char* const wl = smem;                                    // 2 weight buffers
+    char* const xl0 = smem + 2 * WBUF;                        // 2 pixel buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / 128;
+    const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    const int P = a.go.P;
+    const int q0 = a.go.G + mtile * BM;
+    const int NC = a.gi.C / PFmt<PLANES>::CPL;
+    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)(nb * 4) * NC * 9 * 4096), 0, 4 * NC * 9 * 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk2 + (size_t)(nb * 4) * NC * 4096), 0, 4 * NC * 4096, 0x00020000);
+    const int wvoff = lane * 16;
+    // weights of (line c, tap t; t == 9: downsample) -> buffer wb; wave w in 4..7 moves quarter w-4 of each channel tile
+    auto wdma = [&](int c, int t, char* wb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (t < 9) dma16_buf(wrs, wb + j * 4096 + (wave - 4) * 1024, wvoff, ((j * NC + c) * 9 + t) * 4096 + (wave - 4) * 1024);
+            else dma16_buf(wrd, wb + j * 4096 + (wave - 4) * 1024, wvoff, (j * NC + c) * 4096 + (wave - 4) * 1024);
+        }
+    };
+    // pixels of (line c, phase ph) -> buffer xb (waves 0..3)
+    auto xdma = [&](int c, int ph, char* xb) {
+        const int back = ((ph & 2) ? P : 0) + (ph & 1);
+        const char* src = (const char*)a.in + ((size_t)ph * a.in_split_pixels + (size_t)(q0 - back)) * in_pixstride + c * 128;
+        const int npieces = (BM + back) * 8;
+        for (int i0 = wave * 64; i0 < npieces; i0 += 256) {
+            const int i = i0 + lane;
+            const int Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+            dma16(src + (size_t)Pl * in_pixstride + sl * 16, xb + (size_t)i0 * 16);
+        }
+    };
+    auto wread = [&](bf16x8(&w)[NT][4], const char* wb) {
+        const char* src = wb + (wn * 2) * 4096 + lane * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) w[nt][f] = *(const bf16x8*)(src + nt * 4096 + f * 1024);
+            if constexpr (PLANES == 3)
+                w[nt][3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + nt * 4096 + 3 * 1024), 0u, 0u, 0u});
+        }
+    };
+
+    f32x16 acc[NT][MT], accd[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[nt][mt][r] = 0.f; accd[nt][mt][r] = 0.f; }
+
+    // per-phase tap lists: {3x3 tap index (9 = downsample), LDS pixel shift in units of (1, P)}
+    constexpr int NTAP[4] = {2, 2, 2, 4};
+    constexpr int TAPS[4][4] = {{4, 9, 0, 0}, {3, 5, 0, 0}, {1, 7, 0, 0}, {0, 2, 6, 8}};
+    constexpr int SH1[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 0, 0}, {0, 1, 0, 1}};   // + 1 pixel
+    constexpr int SHP[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 1}};   // + P pixels
+
+    if (wave < 4) xdma(0, 0, xl0);
+    else wdma(0, TAPS[0][0], wl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int wpar = 0;                                             // weight buffer of the current step
+    const int m0 = wm * (MT * 32) + l31;                      // this lane's first tile row inside the 256-position tile
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const char* xl = xl0 + (size_t)(ph & 1) * XB;     // 4 items per line: buffer parity = phase parity
+            if (wave < 4) {                                   // next item's pixels: land while this item multiplies
+                if (ph < 3) xdma(c, ph + 1, xl0 + (size_t)((ph + 1) & 1) * XB);
+                else if (c + 1 < NC) xdma(c + 1, 0, xl0);
+            }
+#pragma unroll
+            for (int k = 0; k < NTAP[ph]; ++k) {
+                const int t = TAPS[ph][k];
+                // next step's weights into the other buffer
+                if (wave >= 4) {
+                    if (k + 1 < NTAP[ph]) wdma(c, TAPS[ph][k + 1], wl + (wpar ^ 1) * WBUF);
+                    else if (ph < 3) wdma(c, TAPS[ph + 1][0], wl + (wpar ^ 1) * WBUF);
+                    else if (c + 1 < NC) wdma(c + 1, TAPS[0][0], wl + (wpar ^ 1) * WBUF);
+                }
+                bf16x8 wf[NT][4], xf[MT][4];
+                wread(wf, wl + wpar * WBUF);
+                const int sh = SH1[ph][k] + SHP[ph][k] * P;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int Pl = m0 + mt * 32 + sh;
+                    const int base = lds_xbase(Pl, h);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
+                    if constexpr (PLANES == 3) xf[mt][3] = lds_xscale(xl, base, Pl);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
+                // end of step: the weight waves have only the next step's DMA outstanding; at an item's last step the
+                // pixel waves wait for the next item's pixels
+                if (wave >= 4 || k + 1 == NTAP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                wpar ^= 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = nb * 4 + wn * 2 + nt;
+        conv_epilogue_any<MT, PLANES>(a, acc[nt], q0 + wm * MT * 32, ntile, lane);
+        ConvArgs a2 = a;
+        a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
+        conv_epilogue_any<MT, PLANES>(a2, accd[nt], q0 + wm * MT * 32, ntile, lane);
+    }
+}
+
+template <int PLANES>
+static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 256;
+    if (a.go.C % 128 || a.go.P > 34 || !a.in_split_pixels || !a.out2 || !a.wpk2 || !a.bias2 || a.out_split_pixels) return WSI_EINVAL;
+    const int mtiles = (a.go.NS + BM - 1) / BM, nblocks = a.go.C / 128;
+    const size_t lds = 2 * 16384 + 2 * 40960;
+    auto k = conv3x3s2_wide_kernel<PLANES>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
+    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(512), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int g_s2_ablate = 0;
 int g_xcd_order = 0;                                     // 1: ConvArgs.relu |= 512 for multi-channel-block launches
 int g_s2_small_tiles = 1;                                // r01: 64-pixel tiles measured ~10 % faster (3 workgroups per CU)
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
 int wsi_s2_dispatch(const ConvArgs& a_in, int planes, hipStream_t st) {
     ConvArgs a = a_in;
+    if (a.in_split_pixels)                                   // phase-split input: the wide kernel is the only reader
+        return planes == 3 ? launch_s2wide<3>(a, st) : planes == 2 ? launch_s2wide<2>(a, st) : WSI_EINVAL;
     if (g_xcd_order && a.go.C > 128) a.relu |= 512;
     if (a.gi.C % 64 || a.go.C % 128 || planes < 1 || planes > 3) return WSI_EINVAL;
     if (a.go.H * 2 != a.gi.H || a.go.W * 2 != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
@@ -1340,6 +1518,7 @@ int wsi_s2_dispatch(const ConvArgs& a_in, int planes, hipStream_t st) {
         if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 2, true, 130>(a, st) : launch_s2slab<2, 1, 4, 2, 2, false, 130>(a, st);
         return WSI_EINVAL;                                   // speed mode: gather kernel
     }
+    if (g_s2_ablate && planes == 3 && fuse) return launch_s2slab<2, 1, 4, 3, 3, true, 34, 16>(a, st);   // study build
     if (g_s2_small_tiles) {                                  // 64-pixel tiles: smaller slabs, more workgroups per CU
         if (planes == 3) return fuse ? launch_s2slab<2, 1, 4, 3, 3, true>(a, st) : launch_s2slab<2, 1, 4, 3, 3, false>(a, st);
         if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 3, true>(a, st) : launch_s2slab<2, 1, 4, 2, 3, false>(a, st);
