@@ -723,6 +723,29 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(Con
     }
 }
 
+// one (pixel tile, channel tile, 32-channel line, tap) step of every precision mode
+template <int PLANES>
+static __device__ __forceinline__ void mfma_step(f32x16& d, const bf16x8 (&w)[4], const bf16x8 (&x)[4]) {
+    if constexpr (PLANES == 3) {
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
+        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
+        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
+                                                            __builtin_bit_cast(i32x4, x[3])[0]);
+    } else if constexpr (PLANES == 2) {
+        d = mfma_bf16(w[2], x[0], d);
+        d = mfma_bf16(w[3], x[1], d);
+        d = mfma_bf16(w[0], x[2], d);
+        d = mfma_bf16(w[1], x[3], d);
+        d = mfma_bf16(w[0], x[0], d);
+        d = mfma_bf16(w[1], x[1], d);
+    } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
 // 128 accumulator registers), so a pixel-fragment set read from LDS feeds SIX MFMAs instead of three and the
@@ -732,18 +755,20 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(Con
 // workgroup by LDS-DMA, double-buffered, one barrier per tap; the two waves that share a channel half read them
 // from LDS, the two waves that share a pixel half read the same slab.  No VMEM load returns to registers in the
 // main loop, so vmcnt only ever tracks DMA.
-template <int PLANES, int MINW, int ABL = 0>
-__global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
+// General shape: WM x WN waves, each MT = 4 pixel tiles x NT channel tiles; the default (2, 2, 2) is the 256 px x 128
+// couts form above, (4, 2, 1) = 512 px x 64 couts serves the 64-channel layer 1 (four waves share each weight stage).
+template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, NT = 2, BM = 256, NTHREADS = 256;
+    constexpr int MT = 4, BM = WM * 128, NTHREADS = WM * WN * 64, NTILES = WN * NT, WB = NTILES * 4096;
     constexpr int NF = PLANES == 3 ? 3 : 4;                   // 16-byte fragments per operand set (+ scale dword in mode 3)
-    char* const wl = smem;                                    // 2 x 16 KB weight buffers
-    char* const xl = smem + 32768;                            // pixel slab
+    char* const wl = smem;                                    // 2 weight buffers of NTILES x 4 KB
+    char* const xl = smem + 2 * WB;                           // pixel slab
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
-    const int nblocks = a.go.C / 128;
+    const int nblocks = a.go.C / (NTILES * 32);
     const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
     const int P = a.gi.P;
     const int NC = a.gi.C / PFmt<PLANES>::CPL;
@@ -770,12 +795,15 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
         }
     }
     const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
-    const char* wsrc = (const char*)a.wpk + (size_t)(nb * 4) * NC * 9 * 4096 + (size_t)tid * 16;
-    // weights of (line c, tap t) for the four channel tiles -> buffer wb: thread tid moves piece tid of each tile
+    const char* wsrc = (const char*)a.wpk + (size_t)(nb * NTILES) * NC * 9 * 4096 + (size_t)(tid & 255) * 16;
+    // weights of (line c, tap t) for the workgroup's NTILES channel tiles -> buffer wb: 256 pieces of 16 B per tile
     auto wdma = [&](int c, int t, char* wb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            dma16(wsrc + ((size_t)(j * NC + c) * 9 + t) * 4096, wb + (j * 256 + wave * 64) * 16);
+        for (int p0 = 0; p0 < NTILES * 256; p0 += NTHREADS) {
+            static_assert((NTILES * 256) % NTHREADS == 0, "whole DMA rounds");
+            const int pw = p0 + wave * 64;                   // first piece of this wave's 1 KB chunk (wave-uniform)
+            dma16(wsrc + ((size_t)((pw >> 8) * NC + c) * 9 + t) * 4096, wb + pw * 16);   // piece (tid & 255) of tile pw >> 8
+        }
     };
 
     f32x16 acc[NT][MT];
@@ -793,7 +821,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
         if constexpr (PLANES == 3) x[3] = lds_xscale(xl, base, Pl);
     };
     auto wread = [&](bf16x8(&w)[4], const char* wb, int nt) {
-        const char* src = wb + (wn * 2 + nt) * 4096 + lane * 16;
+        const char* src = wb + (wn * NT + nt) * 4096 + lane * 16;
 #pragma unroll
         for (int f = 0; f < NF; ++f) w[f] = *(const bf16x8*)(src + f * 1024);
         if constexpr (PLANES == 3) w[3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + 3 * 1024), 0u, 0u, 0u});
@@ -808,7 +836,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
             const int sl = sp ^ ((Pl >> 1) & 7);
             dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + sl * 16, xl + (size_t)i0 * 16);
         }
-        wdma(c, 0, wl + kpar * 16384);
+        wdma(c, 0, wl + kpar * WB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int Pc = P;
@@ -817,10 +845,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
         xload(xf[0], xoff[0]);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const char* wb = wl + kpar * 16384;
-            if (t < 8) wdma(c, t + 1, wl + (kpar ^ 1) * 16384);
-            wread(wf[0], wb, 0);
-            wread(wf[1], wb, 1);
+            const char* wb = wl + kpar * WB;
+            if (t < 8) wdma(c, t + 1, wl + (kpar ^ 1) * WB);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wread(wf[nt], wb, nt);
             const int toff = (t / 3) * Pc + (t % 3);
             const int toff_next = ((t + 1) / 3) * Pc + ((t + 1) % 3);
 #pragma unroll
@@ -834,26 +862,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
                 const bf16x8(&x)[4] = xf[k & 1];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8(&w)[4] = wf[nt];
-                    f32x16& d = acc[nt][mt];
-                    if constexpr (PLANES == 3) {
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
-                        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-                        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-                        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                                            __builtin_bit_cast(i32x4, x[3])[0]);
-                    } else if constexpr (PLANES == 2) {
-                        d = mfma_bf16(w[2], x[0], d);
-                        d = mfma_bf16(w[3], x[1], d);
-                        d = mfma_bf16(w[0], x[2], d);
-                        d = mfma_bf16(w[1], x[3], d);
-                        d = mfma_bf16(w[0], x[0], d);
-                        d = mfma_bf16(w[1], x[1], d);
-                    } else {
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
-                    }
+                    mfma_step<PLANES>(acc[nt][mt], wf[nt], x);
                 }
             }
             if (t < 8) {
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = nb * 4 + wn * 2 + nt;
+        const int ntile = nb * NTILES + wn * NT + nt;
         if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
         else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
     }
@@ -1085,17 +1094,17 @@ static int launch_wide2(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-template <int PLANES, int MINW, int ABL = 0>
+template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
 static int launch_wide(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = 256, NTHREADS = 256;
-    if (a.go.C % 128) return WSI_EINVAL;
-    const int nblocks = a.go.C / 128;
+    constexpr int BM = WM * 128, NTHREADS = WM * WN * 64, BN = WN * NT * 32;
+    if (a.go.C % BN) return WSI_EINVAL;
+    const int nblocks = a.go.C / BN;
     const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
     const int mtiles = (int)((R + BM - 1) / BM);
     const size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
-    const size_t lds = 32768 + xbytes;
+    const size_t lds = 2 * (BN / 32) * 4096 + xbytes;
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL>;
+    auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return WSI_EINVAL;
     hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
@@ -1330,29 +1339,6 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
     const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : mtiles * nblocks;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
-}
-
-// one (pixel tile, channel tile, 32-channel line, tap) step of every precision mode
-template <int PLANES>
-static __device__ __forceinline__ void mfma_step(f32x16& d, const bf16x8 (&w)[4], const bf16x8 (&x)[4]) {
-    if constexpr (PLANES == 3) {
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
-        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                            __builtin_bit_cast(i32x4, x[3])[0]);
-    } else if constexpr (PLANES == 2) {
-        d = mfma_bf16(w[2], x[0], d);
-        d = mfma_bf16(w[3], x[1], d);
-        d = mfma_bf16(w[0], x[2], d);
-        d = mfma_bf16(w[1], x[3], d);
-        d = mfma_bf16(w[0], x[0], d);
-        d = mfma_bf16(w[1], x[1], d);
-    } else {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
-    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1606,6 +1592,8 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 / stream families implement mode 3
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
     if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
+    if (cfg == 67) return planes == 3 ? launch_wide<3, 1, 0, 4, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 1, 0, 4, 2, 1>(a, st) : WSI_EINVAL;   // 512 px x 64 couts
+    if (cfg == 68) return planes == 3 ? launch_wide<3, 2, 0, 2, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 2, 0, 2, 2, 1>(a, st) : WSI_EINVAL;   // 256 px x 64 couts
     if (cfg == 62) return planes == 3 ? launch_wide2<3>(a, st) : planes == 2 ? launch_wide2<2>(a, st) : launch_wide2<1>(a, st);
     if (planes == 3 && cfg >= 63 && cfg <= 66) {             // ablations of cfg 62: no weight DMA / no slab DMA / neither / neither + no barriers
         switch (cfg) {
