@@ -8,7 +8,7 @@ import os, sys
 import numpy as np
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import resnet_oracle as R
 from oracle import weights as W
 
