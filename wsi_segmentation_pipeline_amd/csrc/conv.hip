@@ -106,6 +106,7 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
+    const float lo_clamp = (a.relu & 1) ? 0.f : -65504.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * 128;
@@ -131,8 +132,7 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
         f16x8 hv[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (a.relu & 1) v[r] = fmaxf(v[r], 0.f);
-            v[r] = fminf(fmaxf(v[r], -65504.f), 65504.f);
+            v[r] = __builtin_amdgcn_fmed3f(v[r], lo_clamp, 65504.f);              // ReLU (if any) + fp16-range clamp in one op
             const _Float16 hh = (_Float16)v[r];
             hv[r >> 3][r & 7] = hh;
             lo[r] = v[r] - (float)hh;
@@ -1563,6 +1563,8 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(21, 4, 2, 2, 2, false) \
     X(25, 2, 2, 4, 3, false) \
     X(27, 4, 4, 2, 1, false) \
+    X(28, 2, 2, 2, 3, true) \
+    X(29, 2, 2, 2, 4, true) \
     X(39, 4, 4, 2, 1, true) \
     X(26, 4, 1, 2, 3, false) \
     X(30, 4, 1, 4, 2, true) \
