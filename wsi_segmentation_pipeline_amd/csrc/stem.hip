@@ -368,7 +368,12 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
         if (py >= py0) {
             // horizontal 3-max: pooled column px0+j sits on odd lane 2j+1 of each 32-lane half
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], fmaxf(__shfl_up(v[r], 1), __shfl_down(v[r], 1)));
+            for (int r = 0; r < 16; ++r) {                               // neighbours by DPP wave shifts (VALU, no LDS crossbar)
+                const int vi = __builtin_bit_cast(int, v[r]);
+                const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xf, 0xf, false));   // lane i <- i-1
+                const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xf, 0xf, false));   // lane i <- i+1
+                v[r] = fmaxf(v[r], fmaxf(up, dn));
+            }
             const int j = (l31 - 1) >> 1, px = px0 + j;
             const bool store = (l31 & 1) && l31 <= 29 && px < Wp;
             char* o = (char*)A.out_pf + (size_t)(go.G + n * go.S + py * go.P + (store ? px : 0)) * pixstride;
