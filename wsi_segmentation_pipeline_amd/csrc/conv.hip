@@ -1357,8 +1357,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     constexpr int MT = 2, NT = 2, BM = 256;
     constexpr int NF = PLANES == 3 ? 3 : 4;
     constexpr int WBUF = 16384, XB = 40960;                   // X: (256 + 34 + 2) pixels rounded to whole 256-thread DMA rounds
-    char* const wl = smem;                                    // 2 weight buffers
-    char* const xl0 = smem + 2 * WBUF;                        // 2 pixel buffers
+    constexpr int NWB = 4;                                    // weight ring: tap g+3 is requested while tap g multiplies, so a
+                                                              // stage has three steps (not one) to arrive from L2
+    char* const wl = smem;                                    // NWB weight buffers
+    char* const xl0 = smem + NWB * WBUF;                      // 2 pixel buffers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -1418,11 +1420,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     constexpr int SH1[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 0, 0}, {0, 1, 0, 1}};   // + 1 pixel
     constexpr int SHP[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 1}};   // + P pixels
 
+    // steps in execution order within a line: (phase, tap); step g of the whole K loop = line g / 10, entry g % 10
+    constexpr int STEP_TAP[10] = {4, 9, 3, 5, 1, 7, 0, 2, 6, 8};
+    const int NG = NC * 10;
+    auto wdma_step = [&](int c, int j) {                      // j may run past 9: wraps into the next line
+        const int cc = c + j / 10, g = cc * 10 + j % 10;
+        if (g < NG) wdma(cc, STEP_TAP[j % 10], wl + (g & (NWB - 1)) * WBUF);
+    };
     if (wave < 4) xdma(0, 0, xl0);
-    else wdma(0, TAPS[0][0], wl);
+    else { wdma_step(0, 0); wdma_step(0, 1); wdma_step(0, 2); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int wpar = 0;                                             // weight buffer of the current step
     const int m0 = wm * (MT * 32) + l31;                      // this lane's first tile row inside the 256-position tile
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -1434,15 +1442,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < NTAP[ph]; ++k) {
+                constexpr int J0[4] = {0, 2, 4, 6};
+                const int j = J0[ph] + k, g = c * 10 + j;     // this step
                 const int t = TAPS[ph][k];
-                // next step's weights into the other buffer
-                if (wave >= 4) {
-                    if (k + 1 < NTAP[ph]) wdma(c, TAPS[ph][k + 1], wl + (wpar ^ 1) * WBUF);
-                    else if (ph < 3) wdma(c, TAPS[ph + 1][0], wl + (wpar ^ 1) * WBUF);
-                    else if (c + 1 < NC) wdma(c + 1, TAPS[0][0], wl + (wpar ^ 1) * WBUF);
-                }
+                if (wave >= 4) wdma_step(c, j + 3);           // three steps ahead
                 bf16x8 wf[NT][4], xf[MT][4];
-                wread(wf, wl + wpar * WBUF);
+                wread(wf, wl + (g & (NWB - 1)) * WBUF);
                 const int sh = SH1[ph][k] + SHP[ph][k] * P;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -1456,11 +1461,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
-                // end of step: the weight waves have only the next step's DMA outstanding; at an item's last step the
-                // pixel waves wait for the next item's pixels
-                if (wave >= 4 || k + 1 == NTAP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // end of step g: step g+1's weights must be in LDS; the weight waves may leave the two younger stages
+                // (4 DMA instructions each) in flight.  At an item's last step the pixel waves wait for the next item.
+                if (wave >= 4) {
+                    if (g + 3 < NG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (k + 1 == NTAP[ph]) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __syncthreads();
-                wpar ^= 1;
             }
         }
     }
@@ -1479,7 +1488,7 @@ static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     if (a.go.C % 128 || a.go.P > 34 || !a.in_split_pixels || !a.out2 || !a.wpk2 || !a.bias2 || a.out_split_pixels) return WSI_EINVAL;
     const int mtiles = (a.go.NS + BM - 1) / BM, nblocks = a.go.C / 128;
-    const size_t lds = 2 * 16384 + 2 * 40960;
+    const size_t lds = 4 * 16384 + 2 * 40960;
     auto k = conv3x3s2_wide_kernel<PLANES>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
     hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(512), lds, st, a);
