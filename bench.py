@@ -51,7 +51,7 @@ def main():
     ap.add_argument('--tiles', type=int, default=TILES_PER_GPU, help='tiles per GPU per step')
     ap.add_argument('--chunks', type=str, default='', help='stem_chunk,layer1_chunk sub-batch sizes (default: library default)')
     ap.add_argument('--stem', type=str, default='', help='fused,rows_per_seg for the stem kernel (A/B)')
-    ap.add_argument('--s2', type=int, default=-1, help='1 = phase-slab stride-2 kernel with fused downsample, 0 = gather kernels (A/B)')
+    ap.add_argument('--s2', type=int, default=-1, help='wsi_conv_set_mode value for A/B runs (see include/wsi_hip.h)')
     ap.add_argument('--streams', type=int, default=1, help='batches in flight (HIP streams); >1 distorts per-kernel timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='disable per-launch HIP events (roofline leg)')
@@ -170,7 +170,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import resnet_oracle as R
-        nsample = 32
+        nsample = 128                                    # ~1.3 s per pass at ~100 patches/s: 2 thread settings x (1 + 3) passes = 10-15 s
         xy = tiles[:nsample]
         u8 = torch.stack([level0[y:y + TILE, x:x + TILE] for x, y in xy]).permute(0, 3, 1, 2).contiguous().cpu().numpy()
         avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
