@@ -419,6 +419,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         mtile = (blockIdx.x / per) * 8 + (r & 7);
         const int mtiles = DENSE ? (a.gi.N * a.gi.H * a.gi.W + BM - 1) / BM : (a.gi.NS + BM - 1) / BM;
         if (mtile >= mtiles) return;
+    } else if (a.relu & 16384) {
+        // XCD-contiguous ranges: XCD x (= id & 7) walks tiles [x*chunk, (x+1)*chunk) in dispatch order, so the halo rows
+        // two neighbouring pixel tiles share are still in THAT XCD's L2 when the second one asks for them
+        const int chunk = gridDim.x >> 3, lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        nb = lin % nblocks;
+        mtile = lin / nblocks;
+        const int mtiles = DENSE ? (a.gi.N * a.gi.H * a.gi.W + BM - 1) / BM : (a.gi.NS + BM - 1) / BM;
+        if (mtile >= mtiles) return;
     }
     const int P = a.gi.P;
     const int ntile = nb * WN + wn;
@@ -563,7 +571,7 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
-    const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : mtiles * nblocks;
+    const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : (a.relu & 16384) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
@@ -769,7 +777,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int nblocks = a.go.C / (NTILES * 32);
-    const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    if (a.relu & 16384) {                                      // XCD-contiguous tile ranges (see conv3x3s1_slab3_kernel)
+        const int chunk = gridDim.x >> 3, lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        nb = lin % nblocks;
+        mtile = lin / nblocks;
+        if (mtile >= (a.gi.N * a.gi.H * a.gi.W + BM - 1) / BM) return;
+    }
     const int P = a.gi.P;
     const int NC = a.gi.C / PFmt<PLANES>::CPL;
     const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
@@ -1107,7 +1121,8 @@ static int launch_wide(const ConvArgs& a, hipStream_t st) {
     auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return WSI_EINVAL;
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
+    const int grid = (a.relu & 16384) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
@@ -1496,6 +1511,7 @@ static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
 }
 
 int g_s2_ablate = 0;
+int g_xcd_ranges = 2;                                    // XCD-contiguous tile ranges: 1 = the 64-channel layer only, 2 = every stride-1 layer (r01: ~-1 % overall)
 int g_xcd_order = 0;                                     // 1: ConvArgs.relu |= 512 for multi-channel-block launches
 int g_s2_small_tiles = 1;                                // r01: 64-pixel tiles measured ~10 % faster (3 workgroups per CU)
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
@@ -1599,6 +1615,7 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
 int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !(a.relu & ~3)) a.relu |= 512;     // slab3 family only
+    if (g_xcd_ranges && !(a.relu & ~3) && ((cfg >= 20 && cfg < 40) || cfg == 60) && (g_xcd_ranges == 2 || a.go.C == 64)) a.relu |= 16384;
     if (planes == 3 && cfg < 20) return WSI_EINVAL;
     if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 / stream families implement mode 3
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
