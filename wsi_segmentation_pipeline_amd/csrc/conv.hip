@@ -17,6 +17,20 @@
 // --------------------------------------------------------------------------------------------
 // Fused epilogue: bias (+ residual) (+ ReLU), split to bf16 planes, store.  acc[mt] covers
 // pixels q_base + mt*32 + (lane&31) and channels ntile*32 + 8g + 4h + i.
+// --------------------------------------------------------------------------------------------
+// 16-byte LDS-DMA: lane i writes LDS [lds_wave_base + 16*i] from its own global address.
+static __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Buffer-addressed form: source = resource base + 32-bit per-lane byte offset + scalar offset (no
+// 64-bit address VALU).  Kept in a plain __device__ function: used directly inside a kernel
+// template, this builtin makes hipcc's host pass drop the kernel stub (ROCm 7.2).
+static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 template <int MT, int PLANES>
 static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                        const bool (&valid)[MT], int ntile, int lane) {
@@ -96,10 +110,16 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
 // 32 contiguous bytes of fp16 and 8 bytes of each fp4 plane.  Block maxima need one exchange with lane^32; the
 // fp4 planes are swapped between the two lanes so each writes one 16-byte piece (h=0: lo4 of all 32, h=1: hi4).
 // Four store instructions per 32x32 tile (2 x 16 B fp16, 16 B fp4, 4 B scale) and four loads for a residual.
+// Residual: `scratch` (8 KB of LDS private to the wave, or null) selects how the residual tile is read.  Read straight
+// from memory, a load instruction touches 32 different 128-byte lines (one per pixel) and the four loads of a tile cost
+// four TCP look-ups per line: measured 3.8 TB/s on the residual bytes and -18 % on a layer-1 launch when the same bytes
+// are fetched line-contiguously (r01 study).  With scratch the tile (32 lines = 4 KB) is fetched by LDS-DMA, eight lanes
+// per line (pixel indices come from the owning lanes by ds_bpermute; slot swizzle applied on the source side), the
+// next tile's DMA in flight while this one is converted, and each lane then reads its share from LDS.
 template <int MT>
 static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
-                                                        const bool (&valid)[MT], int ntile, int lane) {
-    const int h = lane >> 5;
+                                                        const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
+    const int h = lane >> 5, l31 = lane & 31;
     const size_t pixstride = (size_t)a.go.C * 4;
     float bias[16];
 #pragma unroll
@@ -107,6 +127,18 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
     const float lo_clamp = (a.relu & 1) ? 0.f : -65504.f;
+    const bool via_lds = a.resid && scratch;
+    // DMA of residual tile mt into scratch buffer mt & 1: piece i = j*64 + lane -> pixel (i >> 3) of the tile, slot i & 7
+    auto rdma = [&](int mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pp = 8 * j + (lane >> 3);
+            const int q = __shfl(valid[mt] ? qs[mt] : a.go.G, pp);            // that pixel's PF index (lanes pp and pp+32 agree)
+            const int sl = (lane & 7) ^ ((pp >> 1) & 7);
+            dma16((const char*)a.resid + (size_t)q * pixstride + (size_t)ntile * 128 + sl * 16, scratch + (mt & 1) * 4096 + j * 1024);
+        }
+    };
+    if (via_lds) rdma(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * 128;
@@ -114,10 +146,25 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[mt][r] + bias[r];
         if (a.resid) {
-            const char* rl = (const char*)a.resid + loff;
-            const f16x8 r0 = *(const f16x8*)(rl + 32 * h), r1 = *(const f16x8*)(rl + 32 * h + 16);
-            const uint2 nib = *(const uint2*)(rl + 64 + 8 * h);                     // lo4 of this lane's 16 positions
-            const unsigned rs = *(const unsigned*)(rl + 96) & 255u;                 // residual's scale_lo
+            f16x8 r0, r1;
+            uint2 nib;
+            unsigned rs;
+            if (via_lds) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // tile mt has landed (and the previous tile's stores)
+                if (mt + 1 < MT) rdma(mt + 1);
+                const char* t = scratch + (mt & 1) * 4096 + l31 * 128;
+                const int sw = (l31 >> 1) & 7;
+                r0 = *(const f16x8*)(t + (((2 * h) ^ sw) << 4));
+                r1 = *(const f16x8*)(t + (((2 * h + 1) ^ sw) << 4));
+                nib = *(const uint2*)(t + ((4 ^ sw) << 4) + 8 * h);
+                rs = *(const unsigned*)(t + ((6 ^ sw) << 4)) & 255u;
+            } else {
+                const char* rl = (const char*)a.resid + loff;
+                r0 = *(const f16x8*)(rl + 32 * h);
+                r1 = *(const f16x8*)(rl + 32 * h + 16);
+                nib = *(const uint2*)(rl + 64 + 8 * h);                              // lo4 of this lane's 16 positions
+                rs = *(const unsigned*)(rl + 96) & 255u;                             // residual's scale_lo
+            }
             const float rscale = rs ? mx4_scale_value((int)rs) : 0.f;
             float d[16];
             mx4_unpack8(nib.x, rscale, d);
@@ -226,20 +273,6 @@ static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128
 static __device__ __forceinline__ bf16x8 lds_xscale(const char* smem, int base, int Pl) {
     const unsigned sc = *(const unsigned*)(smem + (base ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1)));
     return __builtin_bit_cast(bf16x8, u32x4{sc, 0u, 0u, 0u});
-}
-
-// --------------------------------------------------------------------------------------------
-// 16-byte LDS-DMA: lane i writes LDS [lds_wave_base + 16*i] from its own global address.
-static __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// Buffer-addressed form: source = resource base + 32-bit per-lane byte offset + scalar offset (no
-// 64-bit address VALU).  Kept in a plain __device__ function: used directly inside a kernel
-// template, this builtin makes hipcc's host pass drop the kernel stub (ROCm 7.2).
-static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 // Stride-1 3x3: the input pixels a tile of BM consecutive PF positions needs form ONE contiguous
@@ -545,8 +578,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             }
         }
     }
-    if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
-    else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
+    if constexpr (PLANES == 3) {
+        char* scratch = nullptr;
+        if (a.resid && !(a.relu & 65536)) {                   // slab memory becomes the waves' residual staging (bit 65536: A/B off)
+            __syncthreads();                                  // every wave is done reading pixel fragments
+            scratch = smem + wave * 8192;
+        }
+        conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane, scratch);
+    } else {
+        conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
+    }
 }
 
 template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0>
@@ -564,7 +605,8 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
         mtiles = (a.gi.NS + BM - 1) / BM;
         maxpix = BM + 2 * a.gi.P + 2;
     }
-    const size_t lds = (size_t)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    size_t lds = (size_t)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    if (lds < (size_t)WM * WN * 8192) lds = (size_t)WM * WN * 8192;          // the epilogue stages residual tiles there (8 KB per wave)
     if (lds > 160 * 1024) return WSI_EINVAL;
     auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE, ABL>;
     if (lds > 64 * 1024) {
@@ -886,10 +928,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
             kpar ^= 1;
         }
     }
+    char* scratch = nullptr;
+    if (PLANES == 3 && a.resid && !(a.relu & 65536)) {        // slab memory becomes the waves' residual staging (epilogue_mx)
+        __syncthreads();
+        scratch = xl + wave * 8192;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int ntile = nb * NTILES + wn * NT + nt;
-        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
+        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane, scratch);
         else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
     }
 }
@@ -1115,7 +1162,8 @@ static int launch_wide(const ConvArgs& a, hipStream_t st) {
     const int nblocks = a.go.C / BN;
     const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
     const int mtiles = (int)((R + BM - 1) / BM);
-    const size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    if (xbytes < (size_t)WM * WN * 8192) xbytes = (size_t)WM * WN * 8192;    // residual staging of the epilogue
     const size_t lds = 2 * (BN / 32) * 4096 + xbytes;
     if (lds > 160 * 1024) return WSI_EINVAL;
     auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT>;
