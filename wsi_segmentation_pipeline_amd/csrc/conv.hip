@@ -590,6 +590,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     }
 }
 
+// exact largest slab (pixels) over the dense tiles of BM real pixels
+static long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
+    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+    const int mtiles = (int)((R + BM - 1) / BM);
+    const int HW = a.gi.H * a.gi.W;
+    auto pos = [&](long long i) { const long long n = i / HW, rem = i - n * HW; return (long long)a.gi.G + n * a.gi.S + (rem / a.gi.W) * a.gi.P + rem % a.gi.W; };
+    auto span = [&](int m) { const long long i0 = (long long)m * BM, i1 = (i0 + BM < R ? i0 + BM : R) - 1; return pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1; };
+    long long maxpix = span(mtiles - 1);
+    const int scan = mtiles < 4 * HW ? mtiles : 4 * HW;      // BM*HW pixels cover every phase of (tile start mod H*W)
+    for (int m = 0; m < scan; ++m) { const long long px = span(m); if (px > maxpix) maxpix = px; }
+    return maxpix;
+}
+
 template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0>
 static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
@@ -599,8 +612,7 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     if (DENSE) {
         const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
         mtiles = (int)((R + BM - 1) / BM);
-        // BM real pixels span at most BM + one pad per started row + one pad row per image crossing
-        maxpix = BM + (BM + a.gi.W - 1) / a.gi.W + 1 + ((BM + a.gi.H * a.gi.W - 1) / (a.gi.H * a.gi.W) + 1) * a.gi.P + 2 * a.gi.P + 2;
+        maxpix = (int)dense_max_slab_pixels(a, BM);          // exact (a bound of BM + pads + 2P + 2 costs a workgroup per CU at 64x64 maps)
     } else {
         mtiles = (a.gi.NS + BM - 1) / BM;
         maxpix = BM + 2 * a.gi.P + 2;
@@ -1125,18 +1137,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_wide2_kernel(ConvArgs a) {
         if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
         else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
     }
-}
-
-static long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
-    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
-    const int mtiles = (int)((R + BM - 1) / BM);
-    const int HW = a.gi.H * a.gi.W;
-    auto pos = [&](long long i) { const long long n = i / HW, rem = i - n * HW; return (long long)a.gi.G + n * a.gi.S + (rem / a.gi.W) * a.gi.P + rem % a.gi.W; };
-    auto span = [&](int m) { const long long i0 = (long long)m * BM, i1 = (i0 + BM < R ? i0 + BM : R) - 1; return pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1; };
-    long long maxpix = span(mtiles - 1);
-    const int scan = mtiles < 4 * HW ? mtiles : 4 * HW;      // BM*HW pixels cover every phase of (tile start mod H*W)
-    for (int m = 0; m < scan; ++m) { const long long px = span(m); if (px > maxpix) maxpix = px; }
-    return maxpix;
 }
 
 template <int PLANES, int ABL = 0>
