@@ -1414,12 +1414,12 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
 // phase 00: tap (1,1) + the downsample tap; 01: (1,0) (1,2); 10: (0,1) (2,1); 11: (0,0) (0,2) (2,0) (2,2).  The
 // next item's pixels are fetched while the current one multiplies (two slab buffers); waves 0-3 issue the pixel
 // DMA, waves 4-7 the weight DMA, so each wave's in-order vmcnt tracks one kind only.  One barrier per tap.
-template <int PLANES>
+template <int PLANES, bool DENSE>
 __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 2, NT = 2, BM = 256;
     constexpr int NF = PLANES == 3 ? 3 : 4;
-    constexpr int WBUF = 16384, XB = 40960;                   // X: (256 + 34 + 2) pixels rounded to whole 256-thread DMA rounds
+    constexpr int WBUF = 16384, XB = 45056;                   // X: up to 352 pixels (256 real ones + their pads + P + 1), whole DMA rounds
     constexpr int NWB = 4;                                    // weight ring: tap g+3 is requested while tap g multiplies, so a
                                                               // stage has three steps (not one) to arrive from L2
     char* const wl = smem;                                    // NWB weight buffers
@@ -1431,7 +1431,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     const int nblocks = a.go.C / 128;
     const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
     const int P = a.go.P;
-    const int q0 = a.go.G + mtile * BM;
+    // dense tile: 256 REAL output pixels (raster order); the pixels a phase needs are still one contiguous PF range,
+    // from the first pixel (minus the phase's back-shift) to the last; no MFMA work on pad positions
+    int q0, qlast, qs[MT];
+    bool valid[MT];
+    if constexpr (!DENSE) {                                   // tiny maps (a dense tile would span too many pad rows): 256 consecutive positions
+        q0 = a.go.G + mtile * BM;
+        qlast = q0 + BM - 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            qs[mt] = q0 + wm * MT * 32 + mt * 32 + l31;
+            valid[mt] = pf_is_pixel(a.go, qs[mt]);
+        }
+    } else {
+        const int HW = a.go.H * a.go.W, R = a.go.N * HW;
+        auto pos = [&](int i) {
+            const int n = i / HW, rem = i - n * HW;
+            const int y = rem / a.go.W, x = rem - y * a.go.W;
+            return a.go.G + n * a.go.S + y * P + x;
+        };
+        const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
+        q0 = pos(i0);
+        qlast = pos(i1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            valid[mt] = i < R;
+            qs[mt] = pos(valid[mt] ? i : i1);
+        }
+    }
     const int NC = a.gi.C / PFmt<PLANES>::CPL;
     const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1451,7 +1479,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     auto xdma = [&](int c, int ph, char* xb) {
         const int back = ((ph & 2) ? P : 0) + (ph & 1);
         const char* src = (const char*)a.in + ((size_t)ph * a.in_split_pixels + (size_t)(q0 - back)) * in_pixstride + c * 128;
-        const int npieces = (BM + back) * 8;
+        const int npieces = (qlast - q0 + 1 + back) * 8;
         for (int i0 = wave * 64; i0 < npieces; i0 += 256) {
             const int i = i0 + lane;
             const int Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
@@ -1494,7 +1522,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     else { wdma_step(0, 0); wdma_step(0, 1); wdma_step(0, 2); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int m0 = wm * (MT * 32) + l31;                      // this lane's first tile row inside the 256-position tile
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
@@ -1514,7 +1541,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 const int sh = SH1[ph][k] + SHP[ph][k] * P;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int Pl = m0 + mt * 32 + sh;
+                    const int Pl = qs[mt] - q0 + sh;
                     const int base = lds_xbase(Pl, h);
 #pragma unroll
                     for (int f = 0; f < NF; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
@@ -1539,20 +1566,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int ntile = nb * 4 + wn * 2 + nt;
-        conv_epilogue_any<MT, PLANES>(a, acc[nt], q0 + wm * MT * 32, ntile, lane);
         ConvArgs a2 = a;
         a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
-        conv_epilogue_any<MT, PLANES>(a2, accd[nt], q0 + wm * MT * 32, ntile, lane);
+        if constexpr (PLANES == 3) {
+            conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
+            conv_epilogue_mx<MT>(a2, accd[nt], qs, valid, ntile, lane);
+        } else {
+            conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
+            conv_epilogue_q<MT, PLANES>(a2, accd[nt], qs, valid, ntile, lane);
+        }
     }
 }
 
 template <int PLANES>
 static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = 256;
+    constexpr int BM = 256, XB = 45056;
     if (a.go.C % 128 || a.go.P > 34 || !a.in_split_pixels || !a.out2 || !a.wpk2 || !a.bias2 || a.out_split_pixels) return WSI_EINVAL;
-    const int mtiles = (a.go.NS + BM - 1) / BM, nblocks = a.go.C / 128;
-    const size_t lds = 4 * 16384 + 2 * 40960;
-    auto k = conv3x3s2_wide_kernel<PLANES>;
+    const long long R = (long long)a.go.N * a.go.H * a.go.W;
+    const int nblocks = a.go.C / 128;
+    // dense tiles if the span of 256 real pixels (+ the largest phase back-shift) fits one pixel buffer
+    ConvArgs g = a;
+    g.gi = a.go;
+    const long long span = dense_max_slab_pixels(g, BM) - (a.go.P + 1);          // that helper adds 2P + 2 of halo; a phase needs P + 1
+    const bool dense = (span * 8 + 255) / 256 * 256 * 16 <= XB;
+    const int mtiles = dense ? (int)((R + BM - 1) / BM) : (a.go.NS + BM - 1) / BM;
+    const size_t lds = 4 * 16384 + 2 * XB;
+    auto k = dense ? conv3x3s2_wide_kernel<PLANES, true> : conv3x3s2_wide_kernel<PLANES, false>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
     hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(512), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
