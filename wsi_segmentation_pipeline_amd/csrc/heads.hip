@@ -64,13 +64,34 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const void* in, PFGeom 
     const size_t pixstride = (size_t)g.C * PFmt<PLANES>::BPC;
     const float inv = 1.0f / (float)(g.H * g.W);
     if constexpr (PLANES == 3) {
+        // Thread t owns one 16-byte slice (8 line positions) of 32-channel line (t >> 2) mod NL, for pixels t / (4 NL),
+        // + 256 / (4 NL), ...: whole lines are read by 4 neighbouring lanes (coalesced 64 B of fp16 + their fp4 / scale),
+        // partial sums meet in LDS.  (The per-channel form read 2 bytes per access: 0.125 ms per 1000 patches.)
+        const int NL = g.C / 32, HW = g.H * g.W;
+        float* part = f + g.C;                                  // [256 / (4 NL) pixel groups][C] partial sums (launcher sizes it)
+        const int slice = tid & 3, line = (tid >> 2) % NL, pg = tid / (4 * NL), npg = 256 / (4 * NL);
+        float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pg < npg) {
+            for (int p = pg; p < HW; p += npg) {
+                const int y = p / g.W, x = p - y * g.W;
+                const char* L = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * pixstride + (size_t)line * 128;
+                const f16x8 hi = *(const f16x8*)(L + 16 * slice);
+                const unsigned lo4 = *(const unsigned*)(L + 64 + 4 * slice);          // positions 8*slice .. 8*slice+7
+                const unsigned sl = *(const unsigned*)(L + 96) & 255u;
+                float d[8];
+                mx4_unpack8(lo4, sl ? mx4_scale_value((int)sl) : 0.f, d);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sm[i] += (float)hi[i] + d[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[pg * g.C + line * 32 + mx_line_chan(8 * slice + i)] = sm[i];
+        }
+        __syncthreads();
         for (int c = tid; c < g.C; c += 256) {
-            float sm = 0.f;
-            for (int y = 0; y < g.H; ++y)
-                for (int x = 0; x < g.W; ++x)
-                    sm += mx_line_decode((const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * pixstride + (size_t)(c >> 5) * 128, c & 31);
-            f[c] = sm * inv;
-            if (feat) feat[(size_t)n * g.C + c] = sm * inv;
+            float t = 0.f;
+            for (int k = 0; k < npg; ++k) t += part[k * g.C + c];
+            f[c] = t * inv;
+            if (feat) feat[(size_t)n * g.C + c] = t * inv;
         }
     } else
     for (int c4 = tid; c4 < g.C / 4; c4 += 256) {
@@ -218,7 +239,11 @@ static int grid_for(long long total) {
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
                             float* logits, int planes, hipStream_t st) {
     if (g.C % 4 || g.N <= 0 || planes < 1 || planes > 3 || (planes == 3 && g.C % 32)) return WSI_EINVAL;
-    const size_t lds = (size_t)g.C * 4;
+    size_t lds = (size_t)g.C * 4;
+    if (planes == 3) {                                      // + partial sums of the 256 / (4 C/32) pixel groups
+        if (g.C > 2048) return WSI_EINVAL;
+        lds += (size_t)(256 / (4 * (g.C / 32))) * g.C * 4;
+    }
     if (planes == 3)
         hipLaunchKernelGGL(avgpool_fc_kernel<3>, dim3(g.N), dim3(256), lds, st, in, g, w, b, K, feat, logits);
     else if (planes == 2)
