@@ -185,3 +185,24 @@ def test_unfused_reference_kernels_agree(dev, sd):
         lib.wsi_stem_set_mode(1, 32)
         lib.wsi_conv_set_mode(1)
     assert float((alt - base).abs().max()) <= 1e-4
+
+
+def test_ab_switches_agree(dev, sd):
+    """Every A/B route of wsi_conv_set_mode (phase-slab vs wide stride-2 kernel, slab3 vs wide stride-1 kernel, XCD
+    orders, 128-pixel stride-2 tiles) gives the same logits up to summation order."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    u8 = W.make_u8_patches(78, (5, 3, 128, 128))
+    x = R.normalize_u8(u8).to(dev)
+    for planes, tol in ((3, 2e-4), (2, 2e-5)):
+        eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']))
+        base = eng.forward_f32(x, logits=True)[1].clone()
+        try:
+            for mode in (3, 1 + 8, 1 + 16, 1 + 32, 1 + 128, 1 + 256, 1 + 512, 3 + 32 + 128 + 256):
+                native.check(lib.wsi_conv_set_mode(mode), 'conv mode')
+                alt = eng.forward_f32(x, logits=True)[1].clone()
+                err = float((alt - base).abs().max())
+                assert err <= tol, (planes, mode, err)
+        finally:
+            lib.wsi_conv_set_mode(1)
