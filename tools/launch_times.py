@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--planes', type=int, default=3)
     ap.add_argument('--n', type=int, default=1000)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--tile', type=int, default=256, help='patch size (multiple of 32)')
     ap.add_argument('--stem-rows', type=int, default=0, help='pooled rows per stem workgroup (default: library default)')
     ap.add_argument('--s2', type=int, default=-1, help='wsi_conv_set_mode value (0 gather, 1 slab with 64-pixel tiles, 3 slab with 128-pixel tiles)')
     args = ap.parse_args()
@@ -35,14 +36,15 @@ def main():
     eng = TrunkEngine(sd, dev, planes=args.planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.n)
     g = torch.Generator(device=dev).manual_seed(3)
     side = int(np.ceil(np.sqrt(args.n)))
-    slide = torch.randint(0, 256, (side * 256, side * 256, 3), dtype=torch.uint8, device=dev, generator=g)
-    xy = torch.tensor([[256 * (i % side), 256 * (i // side)] for i in range(args.n)], dtype=torch.int32, device=dev)
-    eng.forward_tiles(slide, xy, 256, 256, logits=True)
+    T = args.tile
+    slide = torch.randint(0, 256, (side * T, side * T, 3), dtype=torch.uint8, device=dev, generator=g)
+    xy = torch.tensor([[T * (i % side), T * (i // side)] for i in range(args.n)], dtype=torch.int32, device=dev)
+    eng.forward_tiles(slide, xy, T, T, logits=True)
     torch.cuda.synchronize()
     cap = 64 * args.reps
     native.check(lib.wsi_prof_begin(cap), 'prof')
     for _ in range(args.reps):
-        eng.forward_tiles(slide, xy, 256, 256, logits=True)
+        eng.forward_tiles(slide, xy, T, T, logits=True)
     torch.cuda.synchronize()
     ms = np.zeros(cap, np.float32); kind = np.zeros(cap, np.int32); fl = np.zeros(cap, np.float64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -52,7 +54,7 @@ def main():
     med = np.median(m, 0)
     for i in range(per):
         print('%2d %-16s %7.3f ms  %7.1f TFLOP/s' % (i, NAMES.get(int(kind[i]), '?'), med[i], fl[i] / med[i] / 1e9))
-    print('sum of kernels %.3f ms per batch of %d  -> %.0f patches/s (kernel time only)' % (med.sum(), args.n, args.n / med.sum() * 1e3))
+    print('sum of kernels %.3f ms per batch of %d %dx%d patches -> %.0f patches/s (kernel time only)' % (med.sum(), args.n, T, T, args.n / med.sum() * 1e3))
 
 
 if __name__ == '__main__':
