@@ -31,10 +31,23 @@ static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// Residual tile (32 pixels x one 128-byte line) -> 4 KB of LDS at dst by LDS-DMA, eight lanes per line: piece
+// i = j*64 + lane is slot (i & 7) of tile pixel i >> 3, stored swizzled like the pixel slabs (source-side XOR).  q = this
+// lane's own pixel (PF index; lanes p and p+32 hold the same); the owning lanes hand it out by ds_bpermute.
+static __device__ __forceinline__ void resid_tile_dma(const void* resid, int q_own, size_t pixstride, size_t line_off, int lane, char* dst) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pp = 8 * j + (lane >> 3);
+        const int q = __shfl(q_own, pp);
+        const int sl = (lane & 7) ^ ((pp >> 1) & 7);
+        dma16((const char*)resid + (size_t)q * pixstride + line_off + sl * 16, dst + j * 1024);
+    }
+}
+
 template <int MT, int PLANES>
 static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
-                                                       const bool (&valid)[MT], int ntile, int lane) {
-    const int h = lane >> 5;
+                                                       const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
+    const int h = lane >> 5, l31 = lane & 31;
     const size_t pixstride = (size_t)a.go.C * PFmt<PLANES>::BPC;
     const size_t chan_off = (size_t)ntile * (32 * PFmt<PLANES>::BPC) + (size_t)(4 * h) * 2;
     size_t poff[MT], ooff[MT];
@@ -44,9 +57,13 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
         ooff[mt] = a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, valid[mt] ? qs[mt] : a.go.G, pixstride) + chan_off : poff[mt];
     }
 
-    // phase 1: every residual load of the tile in flight at once (branch-free)
+    // residual: with `scratch` (8 KB of wave-private LDS, split precision) tile by tile through LDS-DMA, line-contiguous
+    // (see conv_epilogue_mx); otherwise every residual load of the tile in flight at once (branch-free)
+    const bool via_lds = PLANES == 2 && a.resid && scratch;
     bf16x4 rh[MT][4], rl[MT][4];
-    if (a.resid) {
+    if (via_lds) {
+        resid_tile_dma(a.resid, valid[0] ? qs[0] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch);
+    } else if (a.resid) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -69,6 +86,18 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
     // phase 2: bias + residual + ReLU, split, store
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if (via_lds) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // tile mt has landed (and the previous tile's stores)
+            if (mt + 1 < MT)
+                resid_tile_dma(a.resid, valid[mt + 1] ? qs[mt + 1] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch + ((mt + 1) & 1) * 4096);
+            const char* t = scratch + (mt & 1) * 4096 + l31 * 128 + 8 * h;
+            const int sw = (l31 >> 1) & 7;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                rh[mt][g] = *(const bf16x4*)(t + ((g ^ sw) << 4));
+                rl[mt][g] = *(const bf16x4*)(t + (((4 + g) ^ sw) << 4));
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v[4];
@@ -128,15 +157,8 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
         for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
     const float lo_clamp = (a.relu & 1) ? 0.f : -65504.f;
     const bool via_lds = a.resid && scratch;
-    // DMA of residual tile mt into scratch buffer mt & 1: piece i = j*64 + lane -> pixel (i >> 3) of the tile, slot i & 7
-    auto rdma = [&](int mt) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pp = 8 * j + (lane >> 3);
-            const int q = __shfl(valid[mt] ? qs[mt] : a.go.G, pp);            // that pixel's PF index (lanes pp and pp+32 agree)
-            const int sl = (lane & 7) ^ ((pp >> 1) & 7);
-            dma16((const char*)a.resid + (size_t)q * pixstride + (size_t)ntile * 128 + sl * 16, scratch + (mt & 1) * 4096 + j * 1024);
-        }
+    auto rdma = [&](int mt) {                                 // residual tile mt -> scratch buffer mt & 1
+        resid_tile_dma(a.resid, valid[mt] ? qs[mt] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch + (mt & 1) * 4096);
     };
     if (via_lds) rdma(0);
 #pragma unroll
@@ -578,16 +600,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             }
         }
     }
-    if constexpr (PLANES == 3) {
-        char* scratch = nullptr;
-        if (a.resid && !(a.relu & 65536)) {                   // slab memory becomes the waves' residual staging (bit 65536: A/B off)
-            __syncthreads();                                  // every wave is done reading pixel fragments
-            scratch = smem + wave * 8192;
-        }
-        conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane, scratch);
-    } else {
-        conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
+    char* scratch = nullptr;
+    if (PLANES >= 2 && a.resid && !(a.relu & 65536)) {        // slab memory becomes the waves' residual staging (bit 65536: A/B off)
+        __syncthreads();                                      // every wave is done reading pixel fragments
+        scratch = smem + wave * 8192;
     }
+    if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane, scratch);
+    else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane, scratch);
 }
 
 // exact largest slab (pixels) over the dense tiles of BM real pixels
@@ -941,7 +960,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         }
     }
     char* scratch = nullptr;
-    if (PLANES == 3 && a.resid && !(a.relu & 65536)) {        // slab memory becomes the waves' residual staging (epilogue_mx)
+    if (PLANES >= 2 && a.resid && !(a.relu & 65536)) {        // slab memory becomes the waves' residual staging (epilogues)
         __syncthreads();
         scratch = xl + wave * 8192;
     }
@@ -949,7 +968,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     for (int nt = 0; nt < NT; ++nt) {
         const int ntile = nb * NTILES + wn * NT + nt;
         if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane, scratch);
-        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
+        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane, scratch);
     }
 }
 
