@@ -12,7 +12,7 @@
  *     nothing throws, nothing allocates: workspaces are caller-owned
  *   - planes = 2 : bf16x2 split operands, three MFMA passes, meets the 1e-3 logit contract (3e-5)
  *     planes = 3 : fp16 main pass + MX-fp4 block-scaled cross terms (one scale per 32 channels), three MFMA
- *                  instructions per step instead of six; meets the contract with ~3x margin
+ *                  instructions per step instead of six; meets the contract with ~2x margin (4.5e-4; the default)
  *     planes = 1 : single-pass bf16 (speed mode; logit error ~2e-2)
  *   - "PF" = padded-flat activation layout, see wsi_pf_* below and DESIGN.md
  */
@@ -30,7 +30,7 @@ int wsi_hip_abi_version(void);
 
 /* ---- padded-flat layout helpers (host) -------------------------------------------------------
  * pixel (n,y,x) lives at pixel index (W+2) + n*(H+1)*(W+1) + y*(W+1) + x; each pixel holds
- * C*planes bf16.  wsi_pf_bytes = allocation size; a PF buffer must be zero-filled once before
+ * C channels at 2 (planes 1) or 4 (planes 2, 3) bytes per channel, in 128-byte lines.  wsi_pf_bytes = allocation size; a PF buffer must be zero-filled once before
  * first use (kernels never write the pad positions). */
 size_t wsi_pf_bytes(int n, int h, int w, int c, int planes);
 long long wsi_pf_pixel_index(int n, int y, int x, int h, int w);
