@@ -29,7 +29,7 @@ TILE = 256
 TILES_PER_GPU = 10000
 NX = 72                                   # (NX+1)*(NY+1) - 1 = 10 000 for NY = 136
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16, MI355X_MICROARCH.md chip table
-KIND_NAMES = {1: 'conv3x3_s1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool'}
+KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool'}
 
 
 def slide_geometry(n_tiles):
@@ -130,6 +130,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     roofline = None
+    roofline_l1 = None
     per_kind = {}
     if prof_on:
         cap = launches_per_step * args.steps
@@ -145,22 +146,45 @@ def main():
                 tms, tfl = float(ms[:nrec][sel].sum()), float(fl[:nrec][sel].sum())
                 per_kind[name] = {'launches': int(sel.sum()), 'avg_ms': tms / int(sel.sum()),
                                   'tflops': tfl / (tms * 1e-3) / 1e12, 'share_of_step': tms * 1e-3 / dt}
+        # Dominant kernel = the stride-1 3x3 conv of layers 2-4 (9 launches per batch; with the wide kernel of the split modes
+        # ~41 % of the step).  The 64-channel layer 1 runs a different kernel and is HBM-bound: reported beside it.
+        tj = None
+        tpath = os.path.join(ROOT, 'profiles', {2: 'r01_traffic.json', 3: 'r01_traffic_mx.json'}.get(planes, 'none'))
+        if os.path.exists(tpath):
+            # HBM bytes per launch from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE,
+            # collected at batch 1000); scaled to this run's batch
+            tj = json.load(open(tpath))
+
+        def pmc_bytes(substr):
+            if not tj:
+                return None
+            sel = [v for k, v in tj['kernels'].items() if substr in k]
+            if not sel:
+                return None
+            return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / sum(v['launches'] for v in sel) * args.batch / 1000.0)
         if 'conv3x3_s1' in per_kind:
-            ach = per_kind['conv3x3_s1']['tflops']
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', {2: 'r01_traffic.json', 3: 'r01_traffic_mx.json'}.get(planes, 'none'))
-            if os.path.exists(tpath):
-                # HBM bytes per launch from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE,
-                # collected at batch 1000); scaled to this run's batch
-                tj = json.load(open(tpath))
-                traffic = round(tj['conv3x3_s1_hbm_bytes_per_launch'] * args.batch / 1000.0)
-            roofline = {'kernel': 'conv3x3s1_slab3_kernel (13 launches per batch: the stride-1 3x3 convs of layer1-4)',
-                        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            k = per_kind['conv3x3_s1']
+            wide = planes >= 2
+            roofline = {'kernel': ('conv3x3s1_wide_kernel' if wide else 'conv3x3s1_slab3_kernel') +
+                                  ' (9 launches per batch: the stride-1 3x3 convs of layers 2-4)',
+                        'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(k['tflops'] / PEAK_BF16_TFLOPS, 4),
+                        'traffic': pmc_bytes('conv3x3s1_wide' if wide else 'conv3x3s1_slab3_kernel<4, 1, 4'),
                         'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)' % os.path.basename(tpath),
-                        'avg_launch_ms': round(per_kind['conv3x3_s1']['avg_ms'], 4),
+                        'avg_launch_ms': round(k['avg_ms'], 4),
                         'mfma_passes': {2: '6 bf16 K=16 per 32-channel step', 3: '2 fp16 K=16 + 1 MX-fp4 K=64 per 32-channel step',
                                         1: '2 bf16 K=16 per 32-channel step'}[planes]}
+        if 'conv3x3_s1_layer1' in per_kind:
+            k = per_kind['conv3x3_s1_layer1']
+            # algorithmic bytes per launch: input + output (+ residual on every second launch) of a (batch, 64, 64, 64) tensor
+            bpc = 2 if planes == 1 else 4
+            tensor = args.batch * 64 * 64 * 64 * bpc
+            alg = 2.5 * tensor
+            gbs = alg / (k['avg_ms'] * 1e-3) / 1e9
+            roofline_l1 = {'kernel': 'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)', 'bound': 'hbm',
+                           'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                           'traffic': pmc_bytes('conv3x3s1_slab3_kernel<4, 2, 2'), 'algorithmic_bytes_per_launch': round(alg),
+                           'avg_launch_ms': round(k['avg_ms'], 4), 'tflops': round(k['tflops'], 2)}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,7 +228,7 @@ def main():
                                    'fused read+normalise+conv HIP path, float64 stitch + softmax' % args.tiles,
                        'tiles_total': total_tiles, 'batch': args.batch, 'mode': args.mode,
                        'parallelism': 'tile-shard x%d + 1 all-gather' % world},
-            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'kernels': per_kind,
+            'roofline': roofline, 'roofline_layer1': roofline_l1, 'cpu_baseline': cpu_baseline, 'kernels': per_kind,
         }
         print(json.dumps(line))
     if world > 1:

@@ -161,7 +161,8 @@ int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, cons
 /* ---- measurement hook -------------------------------------------------------------------------
  * wsi_prof_begin arms HIP-event timing (on the launch stream) of every conv / stem launch made by
  * wsi_trunk_forward; wsi_prof_end disarms, waits for the events and returns the number of records
- * copied: ms, kind (1 = 3x3 stride 1, 2 = 3x3 stride 2, 3 = 1x1 downsample, 4 = stem+maxpool)
+ * copied: ms, kind (1 = 3x3 stride 1 of layers 2-4, 5 = 3x3 stride 1 of layer 1, 2 = 3x3 stride 2, 3 = 1x1 downsample,
+ * 4 = stem+maxpool)
  * and algorithmic FLOPs (2*M*N*K over real output pixels) per launch. */
 int wsi_prof_begin(int max_records);
 int wsi_prof_end(float* ms_out, int* kind_out, double* flops_out, int cap);

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsi_segmentation_pipeline_amd import native, synthetic as W  # noqa: E402
 from wsi_segmentation_pipeline_amd.engine import TrunkEngine  # noqa: E402
 
-NAMES = {1: 'conv3x3_s1', 2: 'conv3x3_s2(+ds)', 3: 'conv1x1_s2', 4: 'stem+maxpool'}
+NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1', 2: 'conv3x3_s2(+ds)', 3: 'conv1x1_s2', 4: 'stem+maxpool'}
 
 
 def main():

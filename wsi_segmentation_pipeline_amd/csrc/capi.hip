@@ -537,7 +537,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     char* ws = (char*)workspace;
     const int planes = wt->planes;
     int rc = WSI_OK;
-    // kind: 1 = 3x3 stride-1 (slab kernel), 2 = 3x3 stride-2 (gather), 3 = 1x1 downsample, 4 = stem+maxpool;
+    // kind: 1 = 3x3 stride-1 of layers 2-4 (wide kernel), 5 = 3x3 stride-1 of the 64-channel layer 1 (slab3 kernel),
+    // 2 = 3x3 stride-2 (+ fused downsample), 3 = 1x1 downsample, 4 = stem+maxpool;
     // flops = 2*M*N*K over real output pixels (padding taps counted)
 #define PROF_CONV(kind, NN, HO, WO, CI, CO, KK, call)                                                \
     do {                                                                                            \
@@ -579,13 +580,13 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             const int m = (cur + 1) % 3, o = (cur + 2) % 3;
             char *x = ws + p.buf[0][cur] + img_off(0, n1), *mid = ws + p.buf[0][m] + img_off(0, n1),
                  *out = ws + p.buf[0][o] + img_off(0, n1);
-            PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
+            PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
                                                                      H1, W1, 64, 64, 1, 1, planes, st));
             if (b == 1 && split0) {                    // layer1's output feeds only the stride-2 entry of layer2
-                PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act_split(mid, ws + p.buf[0][3], x, wt->conv_w[3], wt->conv_b[3],
+                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act_split(mid, ws + p.buf[0][3], x, wt->conv_w[3], wt->conv_b[3],
                                                                                nn1, H1, W1, 64, 64, 1, planes, st));
             } else {
-                PROF_CONV(1, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
+                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
                                                                          nn1, H1, W1, 64, 64, 1, 1, planes, st));
             }
             cur = o;
