@@ -297,73 +297,6 @@ static __device__ __forceinline__ bf16x8 lds_xscale(const char* smem, int base, 
     return __builtin_bit_cast(bf16x8, u32x4{sc, 0u, 0u, 0u});
 }
 
-// Stride-1 3x3: the input pixels a tile of BM consecutive PF positions needs form ONE contiguous
-// range [q0-P-1, q0+BM+P+1): stage that slab once per 128-byte line by LDS-DMA (all pieces in
-// flight at once, swizzle applied on the source address), then all nine taps are LDS address
-// shifts.  Wave (wm, wn) computes pixels [wm*MT*32, +MT*32) x couts [32*(nb*WN+wn), +32); its
-// weight fragments are prefetched one tap ahead straight into registers.
-template <int MT, int WM, int WN, int PLANES, int MINW>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = WM * MT * 32;
-    constexpr int NTHREADS = WM * WN * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nblocks = a.go.C / (WN * 32);
-    const int nb = blockIdx.x % nblocks;
-    const int mtile = blockIdx.x / nblocks;
-    const int P = a.gi.P;
-    const int q0 = a.gi.G + mtile * BM;
-    const int npieces = (BM + 2 * P + 2) * 8;                 // 16-byte pieces in the slab
-    const int ntile = nb * WN + wn;
-    const int NC = a.gi.C / PFmt<PLANES>::CPL;
-    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
-    const char* in_base = (const char*)a.in + (size_t)(q0 - P - 1) * in_pixstride;
-    const bf16x8* wbase = (const bf16x8*)a.wpk + (size_t)ntile * NC * 9 * 4 * 64 + lane;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-    int xoff[MT];                                             // slab-local pixel of each tile row (tap 0,0 adds toff)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xoff[mt] = wm * MT * 32 + mt * 32 + l31;
-
-    for (int c = 0; c < NC; ++c) {
-        const bf16x8* wp = wbase + (size_t)c * 9 * 4 * 64;
-        bf16x8 wcur[4], wnxt[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) wcur[f] = wp[f * 64];     // tap 0 weights fly during the slab DMA
-        if (c) __syncthreads();                               // every wave is done reading the previous line
-        for (int i0 = wave * 64; i0 < ((a.relu & 4) ? 0 : npieces); i0 += NTHREADS) {
-            const int i = i0 + lane;
-            const int Pl = i >> 3, sp = i & 7;
-            const int s = sp ^ ((Pl >> 1) & 7);
-            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16, smem + (size_t)i0 * 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll 1
-        for (int t = 0; t < 9; ++t) {
-            if (t < 8 && !(a.relu & 16)) {
-#pragma unroll
-                for (int f = 0; f < 4; ++f) wnxt[f] = ((a.relu & 32) ? wbase : wp)[(((a.relu & 32) ? 0 : t + 1) * 4 + f) * 64];
-            }
-            const int toff = (t / 3 - 1) * P + (t % 3 - 1) + P + 1;
-            int xbase[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xbase[mt] = lds_xbase(xoff[mt] + toff, h);
-            if (!(a.relu & 8)) mfma_line<MT, PLANES>(acc, wcur, smem, xbase);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) wcur[f] = wnxt[f];
-        }
-    }
-    conv_epilogue<MT, PLANES>(a, acc, q0 + wm * MT * 32, ntile, lane);
-}
-
 // --------------------------------------------------------------------------------------------
 // Generic gather kernel (3x3 stride 2, 1x1 stride 2, also stride 1): per (line, tap) step the BM
 // input pixels are gathered into an LDS tile by per-lane source addresses.  Pad output positions
@@ -1645,24 +1578,6 @@ int wsi_s2_dispatch(const ConvArgs& a_in, int planes, hipStream_t st) {
     return fuse ? launch_s2slab<4, 1, 4, 1, 2, true>(a, st) : launch_s2slab<4, 1, 4, 1, 2, false>(a, st);
 }
 
-template <int MT, int WM, int WN, int PLANES, int MINW>
-static int launch_slab(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
-    if (a.go.C % (WN * 32)) return WSI_EINVAL;
-    const int mtiles = (a.gi.NS + BM - 1) / BM;
-    const int nblocks = a.go.C / (WN * 32);
-    const int npieces = (BM + 2 * a.gi.P + 2) * 8;
-    const size_t lds = (size_t)((npieces + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;   // whole DMA rounds
-    if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_slab_kernel<MT, WM, WN, PLANES, MINW>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return WSI_EINVAL;
-    }
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
-    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
-}
-
 template <int MT, int WM, int WN, int PLANES>
 static int launch_gather(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32;
@@ -1674,20 +1589,8 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-// Slab tile configurations (cfg index -> MT, WM, WN, min waves/SIMD).  Every wave owns 32 output
-// channels and MT*32 pixels; WN waves share one pixel slab; BM = WM*MT*32, BN = WN*32.
-#define SLAB_CFGS(X)  \
-    X(0, 8, 1, 4, 1)  \
-    X(1, 8, 1, 4, 2)  \
-    X(2, 4, 1, 4, 2)  \
-    X(3, 4, 2, 2, 2)  \
-    X(4, 4, 2, 4, 2)  \
-    X(5, 8, 1, 2, 2)  \
-    X(6, 8, 2, 2, 2)  \
-    X(7, 2, 2, 4, 2)  \
-    X(8, 4, 4, 2, 2)  \
-    X(9, 4, 1, 2, 2)
-
+// Slab tile configurations (cfg index -> MT, WM, WN, min waves/SIMD, dense).  Every wave owns 32 output channels and
+// MT*32 pixels; WN waves share one pixel slab; BM = WM*MT*32, BN = WN*32.  (cfg 0-9, the first slab kernel, are gone.)
 // software-pipelined variants: cfg 20 + index
 #define SLAB3_CFGS(X) \
     X(20, 4, 1, 4, 2, false) \
@@ -1722,8 +1625,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !(a.relu & ~3)) a.relu |= 512;     // slab3 family only
     if (g_xcd_ranges && !(a.relu & ~3) && ((cfg >= 20 && cfg < 40) || cfg == 60) && (g_xcd_ranges == 2 || a.go.C == 64)) a.relu |= 16384;
-    if (planes == 3 && cfg < 20) return WSI_EINVAL;
-    if (planes == 3 && cfg < 20) return WSI_EINVAL;          // only the slab3 / stream families implement mode 3
+    if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
     if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
     if (cfg == 67) return planes == 3 ? launch_wide<3, 1, 0, 4, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 1, 0, 4, 2, 1>(a, st) : WSI_EINVAL;   // 512 px x 64 couts
@@ -1756,10 +1658,6 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     case id: return planes == 3 ? launch_slab3<MT, WM, WN, 3, MINW, DENSE>(a, st) \
                   : planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
         SLAB3_CFGS(X)
-#undef X
-#define X(id, MT, WM, WN, MINW) \
-    case id: return planes == 2 ? launch_slab<MT, WM, WN, 2, MINW>(a, st) : launch_slab<MT, WM, WN, 1, MINW>(a, st);
-        SLAB_CFGS(X)
 #undef X
     }
     return WSI_EINVAL;
