@@ -257,3 +257,38 @@ def test_phase_split_stride2_block(dev, shape):
         if planes == 3:
             real = E.pf_pack(torch.ones_like(g3).to(dev), 3).view(-1, 128)[:, :64].ne(0).any(1)
             assert not bool(o3.view(-1, 128)[~real].ne(0).any()) and not bool(o1.view(-1, 128)[~real].ne(0).any())
+
+
+def test_phase_split_argument_errors(dev):
+    """The phase-split entry points refuse what the wide stride-2 kernel cannot take (-22 = EINVAL), they never fault."""
+    import ctypes as C
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    lib = native.load()
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    w3 = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    w1 = torch.randn(128, 64, 1, 1, generator=g) * 0.1
+    for planes in (2, 3):
+        wp0, b0 = E.prepack_conv(w0, None, planes, dev)
+        wp3, b3 = E.prepack_conv(w3, None, planes, dev)
+        wp1, b1 = E.prepack_conv(w1, None, planes, dev)
+        buf = torch.zeros(1 << 22, dtype=torch.uint8, device=dev)
+        out = torch.zeros(1 << 22, dtype=torch.uint8, device=dev)
+        ds = torch.zeros(1 << 22, dtype=torch.uint8, device=dev)
+        # odd map size: no phase split
+        assert lib.wsi_pf_split_bytes(1, 7, 8, 64, planes) == 0
+        assert lib.wsi_conv3x3_bn_act_split(buf.data_ptr(), out.data_ptr(), None, wp0.data_ptr(), b0.data_ptr(), 1, 7, 8, 64, 64, 1,
+                                            planes, st()) == -22
+        # output maps wider than 33 (input 80x80 -> 40x40): the wide stride-2 kernel declines, the caller keeps ordinary PF
+        big = torch.zeros(lib.wsi_pf_split_bytes(1, 80, 80, 64, planes), dtype=torch.uint8, device=dev)
+        assert lib.wsi_conv3x3s2_ds_fused_split(big.data_ptr(), out.data_ptr(), ds.data_ptr(), wp3.data_ptr(), b3.data_ptr(),
+                                                wp1.data_ptr(), b1.data_ptr(), 1, 80, 80, 64, 128, planes, st()) == -22
+        # aliasing output pointers
+        assert lib.wsi_conv3x3s2_ds_fused_split(buf.data_ptr(), out.data_ptr(), out.data_ptr(), wp3.data_ptr(), b3.data_ptr(),
+                                                wp1.data_ptr(), b1.data_ptr(), 1, 16, 16, 64, 128, planes, st()) == -22
+    # single-plane (speed) mode has no phase-split path
+    wp0, b0 = E.prepack_conv(w0, None, 1, dev)
+    assert lib.wsi_conv3x3_bn_act_split(buf.data_ptr(), out.data_ptr(), None, wp0.data_ptr(), b0.data_ptr(), 1, 8, 8, 64, 64, 1, 1,
+                                        st()) == -22
+    torch.cuda.synchronize()
