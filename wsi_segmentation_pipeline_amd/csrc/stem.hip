@@ -183,7 +183,7 @@ struct StemPoolArgs {
     int rows_per_seg;        // pooled rows per workgroup
 };
 
-constexpr int SP_COLS = 68;                  // input columns per strip (2*31 + 6)
+constexpr int SP_COLS = 70;                  // input columns per strip (2*31 + 8: the widest lane's 16-byte read)
 constexpr int SP_RING = 16;                  // ring rows
 constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
 
@@ -198,12 +198,16 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = output-channel tile
     const int l31 = lane & 31, h = lane >> 5;
     const int Hc = a.H / 2, Wc = a.W / 2, Hp = a.H / 4, Wp = a.W / 4;
-    const int nstrips = (Wp + 14) / 15, nsegs = (Hp + A.rows_per_seg - 1) / A.rows_per_seg;
+    // Strips: normally 15 pooled columns on the ODD lanes 1..29 (lane = conv column 2*px0 - 1 + lane: the column left of
+    // the first pooled one is lane 0).  Pooled maps up to 16 wide (64x64 patches) fit ONE strip in the EVEN layout: lane =
+    // conv column, pooled column p on lane 2p, whose left neighbour for p = 0 is the padding (lane 0 keeps its own value).
+    const bool even = Wp <= 16;
+    const int nstrips = even ? 1 : (Wp + 14) / 15, nsegs = (Hp + A.rows_per_seg - 1) / A.rows_per_seg;
     int b = blockIdx.x;
     const int strip = b % nstrips; b /= nstrips;
     const int seg = b % nsegs;
     const int n = b / nsegs;
-    const int px0 = strip * 15, c0 = 2 * px0 - 1;                       // first pooled col / first conv col (lane 0)
+    const int px0 = strip * 15, c0 = even ? 0 : 2 * px0 - 1;            // first pooled col / first conv col (lane 0)
     const int py0 = seg * A.rows_per_seg;
     const int py1 = min(py0 + A.rows_per_seg, Hp);
     const int ix0 = 2 * c0 - 3;                                         // input column of LDS column 0
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     float carry[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) carry[r] = 0.f;
-    const bool col_ok = (c0 + l31) >= 0 && (c0 + l31) < Wc && l31 < 31;
-    const int lc = l31 < 31 ? l31 : 30;                                 // lane 31 is idle: keep its reads inside the row
+    const bool col_ok = (c0 + l31) >= 0 && (c0 + l31) < Wc && (even || l31 < 31);
+    const int lc = (even || l31 < 31) ? l31 : 30;                       // odd layout: lane 31 is idle, keep its reads inside the row
     const size_t pixstride = (size_t)64 * PFmt<OUT>::BPC;
     PFGeom go = pf_geom(a.N, Hp, Wp, 64);
 
@@ -370,12 +374,13 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                               // neighbours by DPP wave shifts (VALU, no LDS crossbar)
                 const int vi = __builtin_bit_cast(int, v[r]);
-                const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xf, 0xf, false));   // lane i <- i-1
+                float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xf, 0xf, false));         // lane i <- i-1
+                if (even && l31 == 0) up = v[r];                         // even layout: column -1 is padding (lane 32 must not see lane 31)
                 const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xf, 0xf, false));   // lane i <- i+1
                 v[r] = fmaxf(v[r], fmaxf(up, dn));
             }
-            const int j = (l31 - 1) >> 1, px = px0 + j;
-            const bool store = (l31 & 1) && l31 <= 29 && px < Wp;
+            const int j = even ? (l31 >> 1) : ((l31 - 1) >> 1), px = px0 + j;
+            const bool store = (even ? !(l31 & 1) : ((l31 & 1) && l31 <= 29)) && px < Wp;
             char* o = (char*)A.out_pf + (size_t)(go.G + n * go.S + py * go.P + (store ? px : 0)) * pixstride;
             if constexpr (OUT == 3) {
                 // fp16 hi + MX-fp4 (hi4, lo4) with one scale per 32-channel line; the line's channels sit in lanes l, l^32
@@ -436,7 +441,7 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
     StemPoolArgs A;
     A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg;
     const int Hp = a.H / 4, Wp = a.W / 4;
-    const long long grid = (long long)a.N * ((Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);
+    const long long grid = (long long)a.N * (Wp <= 16 ? 1 : (Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);   // strips, see kernel
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
     const bool u8x = a.mode == 1 && a.wpk_u8 && a.bias_u8 && planes >= 2;
     const size_t lds = (size_t)(planes == 1 || u8x ? 1 : 2) * SP_PLANE;
