@@ -29,6 +29,8 @@ TILE = 256
 TILES_PER_GPU = 10000
 NX = 72                                   # (NX+1)*(NY+1) - 1 = 10 000 for NY = 136
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16, MI355X_MICROARCH.md chip table
+# BASELINE.json's metric, verbatim
+METRIC = 'patches/sec (256\u00d7256\u00d73) whole-slide inference, 1/2/4/8 MI355X + CPU ref'
 KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool'}
 
 
@@ -218,7 +220,7 @@ def main():
 
     if rank == 0:
         line = {
-            'metric': 'patches/sec (256x256x3) whole-slide inference', 'value': round(value, 1), 'unit': 'patches/s',
+            'metric': METRIC, 'value': round(value, 1), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {2: 'bf16x2-split (3 MFMA passes, fp32 accumulate)', 3: 'fp16 + MX-fp4 cross terms (fp32 accumulate)',
