@@ -1470,8 +1470,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         const int cc = c + j / 10, g = cc * 10 + j % 10;
         if (g < NG) wdma(cc, STEP_TAP[j % 10], wl + (g & (NWB - 1)) * WBUF);
     };
+    // Steps run in PAIRS (two taps of one phase) between barriers: the ring's four buffers are two pair slots; the weights
+    // of pair p+1 are requested at the start of pair p (a pair = 24 MFMAs per wave of lead) and waited for at its end.
     if (wave < 4) xdma(0, 0, xl0);
-    else { wdma_step(0, 0); wdma_step(0, 1); wdma_step(0, 2); }
+    else { wdma_step(0, 0); wdma_step(0, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < NC; ++c) {
@@ -1483,34 +1485,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 else if (c + 1 < NC) xdma(c + 1, 0, xl0);
             }
 #pragma unroll
-            for (int k = 0; k < NTAP[ph]; ++k) {
+            for (int kp = 0; kp < NTAP[ph]; kp += 2) {
                 constexpr int J0[4] = {0, 2, 4, 6};
-                const int j = J0[ph] + k, g = c * 10 + j;     // this step
-                const int t = TAPS[ph][k];
-                if (wave >= 4) wdma_step(c, j + 3);           // three steps ahead
-                bf16x8 wf[NT][4], xf[MT][4];
-                wread(wf, wl + (g & (NWB - 1)) * WBUF);
-                const int sh = SH1[ph][k] + SHP[ph][k] * P;
+                const int j0 = J0[ph] + kp;                   // first step of the pair (even)
+                if (wave >= 4) { wdma_step(c, j0 + 2); wdma_step(c, j0 + 3); }   // the next pair
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int Pl = qs[mt] - q0 + sh;
-                    const int base = lds_xbase(Pl, h);
+                for (int k = kp; k < kp + 2; ++k) {
+                    const int g = c * 10 + J0[ph] + k;
+                    const int t = TAPS[ph][k];
+                    bf16x8 wf[NT][4], xf[MT][4];
+                    wread(wf, wl + (g & (NWB - 1)) * WBUF);
+                    const int sh = SH1[ph][k] + SHP[ph][k] * P;
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
-                    if constexpr (PLANES == 3) xf[mt][3] = lds_xscale(xl, base, Pl);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int Pl = qs[mt] - q0 + sh;
+                        const int base = lds_xbase(Pl, h);
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
+                        if constexpr (PLANES == 3) xf[mt][3] = lds_xscale(xl, base, Pl);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
                 }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
-                // end of step g: step g+1's weights must be in LDS; the weight waves may leave the two younger stages
-                // (4 DMA instructions each) in flight.  At an item's last step the pixel waves wait for the next item.
-                if (wave >= 4) {
-                    if (g + 3 < NG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (k + 1 == NTAP[ph]) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                // end of the pair: the weight waves wait for the next pair's stages, the pixel waves (at an item's last pair)
+                // for the next item's pixels
+                if (wave >= 4 || kp + 2 == NTAP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
         }
