@@ -550,7 +550,10 @@ static long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
     auto pos = [&](long long i) { const long long n = i / HW, rem = i - n * HW; return (long long)a.gi.G + n * a.gi.S + (rem / a.gi.W) * a.gi.P + rem % a.gi.W; };
     auto span = [&](int m) { const long long i0 = (long long)m * BM, i1 = (i0 + BM < R ? i0 + BM : R) - 1; return pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1; };
     long long maxpix = span(mtiles - 1);
-    const int scan = mtiles < 4 * HW ? mtiles : 4 * HW;      // BM*HW pixels cover every phase of (tile start mod H*W)
+    int g = BM, r = HW;                                       // tile starts repeat (mod H*W) every H*W / gcd(BM, H*W) tiles
+    while (r) { const int t = g % r; g = r; r = t; }
+    const int period = HW / g + 1;
+    const int scan = mtiles < period ? mtiles : period;
     for (int m = 0; m < scan; ++m) { const long long px = span(m); if (px > maxpix) maxpix = px; }
     return maxpix;
 }
