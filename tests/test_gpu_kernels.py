@@ -292,3 +292,14 @@ def test_phase_split_argument_errors(dev):
     assert lib.wsi_conv3x3_bn_act_split(buf.data_ptr(), out.data_ptr(), None, wp0.data_ptr(), b0.data_ptr(), 1, 8, 8, 64, 64, 1, 1,
                                         st()) == -22
     torch.cuda.synchronize()
+
+
+def test_random_shapes_sweep(dev, monkeypatch):
+    """12 random (n, c, h, w) shapes - non-square maps, odd sizes - through the stride-1 kernels and the phase-split
+    stride-2 block in both split modes (tests/studies/random_conv_shapes.py runs the same sweep at length)."""
+    import os
+    import runpy
+    import sys
+    path = os.path.join(os.path.dirname(__file__), 'studies', 'random_conv_shapes.py')
+    monkeypatch.setattr(sys, 'argv', [path, '3', '12'])
+    runpy.run_path(path, run_name='__main__')
