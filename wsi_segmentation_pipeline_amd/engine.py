@@ -53,7 +53,7 @@ class TrunkEngine:
     state_dict: reference key names (conv1.weight, bn1.*, layerL.B.convK.weight, ...).
     """
 
-    def __init__(self, state_dict, device, planes=MX, head=None, max_batch=256,
+    def __init__(self, state_dict, device, planes=MX, head=None, max_batch=None,
                  mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), streams=1):
         self.lib = native.load()
         self.device = torch.device(device)
@@ -62,7 +62,9 @@ class TrunkEngine:
         if planes not in (1, 2, 3):
             raise ValueError('planes must be 1 (speed), 2 (parity, bf16 split) or 3 (parity, fp16 + MX-fp4)')
         self.planes = planes
-        self.max_batch = int(max_batch)
+        # images per trunk call; None = sized so that every kernel fills the chip several times over (2000 patches of 256x256,
+        # scaled by patch area; the workspace is ~8.3 MB per 256x256 patch: 17 GB of the 288 GB)
+        self.max_batch = None if max_batch is None else int(max_batch)
         # batches of one call are spread round-robin over `streams` HIP streams (own workspace each), so a
         # memory-bound stage of one batch overlaps an MFMA-bound stage of another and grid tails get filled
         self._streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(streams)))] if streams > 1 else []
@@ -190,7 +192,7 @@ class TrunkEngine:
         n, _, h, w = x.shape
         if tap is not None:
             return self._run(n, h, w, x, None, None, False, False, False, tap)
-        return self._batched(n, lambda i, m, slot: self._run(m, h, w, x[i:i + m], None, None, feat, logits, fmap, slot=slot))
+        return self._batched(n, lambda i, m, slot: self._run(m, h, w, x[i:i + m], None, None, feat, logits, fmap, slot=slot), h, w)
 
     def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
         """slide_u8: (SH,SW,3) uint8 GPU tensor (last two dims contiguous); tile_xy: (N,2) int32 GPU tensor of
@@ -207,13 +209,14 @@ class TrunkEngine:
         if tap is not None:
             return self._run(n, ph, pw, None, slide_u8, tile_xy, False, False, False, tap)
         return self._batched(n, lambda i, m, slot: self._run(m, ph, pw, None, slide_u8, tile_xy[i:i + m], feat, logits, fmap,
-                                                             slot=slot))
+                                                             slot=slot), ph, pw)
 
-    def _batched(self, n, run):
+    def _batched(self, n, run, h=256, w=256):
         """Split n images into max_batch chunks; with several chunks, alternate them over the side streams."""
-        starts = list(range(0, n, self.max_batch))
+        mb = self.max_batch if self.max_batch else max(1, int(2000 * 65536 // max(h * w, 1)))
+        starts = list(range(0, n, mb))
         if len(starts) == 1 or not self._streams:
-            outs = [run(i, min(self.max_batch, n - i), 0) for i in starts]
+            outs = [run(i, min(mb, n - i), 0) for i in starts]
         else:
             cur = torch.cuda.current_stream()
             ready = torch.cuda.Event()
@@ -223,7 +226,7 @@ class TrunkEngine:
                 st = self._streams[j % len(self._streams)]
                 st.wait_event(ready)
                 with torch.cuda.stream(st):
-                    outs.append(run(i, min(self.max_batch, n - i), j % len(self._streams)))
+                    outs.append(run(i, min(mb, n - i), j % len(self._streams)))
             for st in self._streams:
                 cur.wait_stream(st)
             for o in outs:                                  # tensors were allocated on side streams
