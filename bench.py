@@ -1,78 +1,142 @@
 #!/usr/bin/env python3
 """Headline benchmark: patches/sec (256x256x3) whole-slide 'cls' inference on MI355X.
 
-Workload (BASELINE.json configs[1]): ResNet-18 trunk + Classifier on a synthetic, HBM-resident
-10 000-tile slide (tile 256, stride 256, reference grid utils/dataset.py:143-166), fused tile read
-+ colour normalisation + conv stack on HIP kernels, per-tile logits stitched into the float64
-level-2 map and pushed through softmax/threshold/heat-map.  One "step" = one full pass over the
-slide.  With N ranks the slide grows to N x 10 000 tiles (weak scaling): the tile list is sharded
-contiguously, logits are exchanged with ONE RCCL all-gather, rank 0 stitches.
+Workloads (BASELINE.json configs):
+  cfg3 (default, every N) ONE 40 000 x 40 000 synthetic slide, tile 256 / stride 256 -> 24 648 tiles (reference grid
+       utils/dataset.py:143-166), the tile list sharded contiguously over the N ranks (STRONG scaling), every rank
+       keeping only the slide regions its own tiles touch resident in HBM (slide.region_plan), ONE RCCL all-gather
+       of the per-tile logits, float64 stitch + softmax / heat map on every rank.
+  cfg2 10 000-tile synthetic slide per GPU (weak scaling; the r01 headline, kept for comparison).
+  cfg4 region-proposal bags: R regions x 16 crops of 64x64 (ResNet.forward bag path, resnets_shift.py:189-217),
+       bags sharded by count over the ranks, ensemble logits gathered (metric: 64x64 crops/s).
+One "step" = one full pass over the slide (or over all bags).  Tile read + colour normalisation + conv stack run
+on the HIP kernels of libwsi_hip.so; inputs are resident in HBM when the timed region starts.
 
-Prints ONE JSON line (contract in the task brief) with `roofline` (3x3 stride-1 conv kernels, HIP
-events on the launch stream, live in the timed region) and `cpu_baseline` (the CPU oracle timed on
-this box's host cores over a bounded sample of the same tiles).
+`python bench.py --gpus N` starts its own N ranks as fresh child processes (the parent never touches a GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it was given.
+
+Prints ONE JSON line with `roofline` (dominant kernel, HIP events on the launch stream, live in the timed region),
+`roofline_layer1`, `roofline_bf16` (the same dominant kernel timed in single-pass bf16, outside the timed region)
+and `cpu_baseline` (the CPU oracle timed on this box's host cores over a bounded sample of the same tiles).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE = 256
-TILES_PER_GPU = 10000
-NX = 72                                   # (NX+1)*(NY+1) - 1 = 10 000 for NY = 136
-PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16, MI355X_MICROARCH.md chip table
+NX = 72                                   # cfg2: (NX+1)*(NY+1) - 1 = 10 000 for NY = 136
+PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16 / fp16, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
 # BASELINE.json's metric, verbatim
-METRIC = 'patches/sec (256\u00d7256\u00d73) whole-slide inference, 1/2/4/8 MI355X + CPU ref'
-KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool'}
+METRIC = 'patches/sec (256×256×3) whole-slide inference, 1/2/4/8 MI355X + CPU ref'
+KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool', 6: 'layer1_block_fused'}
 
 
-def slide_geometry(n_tiles):
-    ny = (n_tiles + 1 + NX) // (NX + 1) - 1
-    while (NX + 1) * (ny + 1) - 1 < n_tiles:
-        ny += 1
-    return 257 + NX * TILE, 257 + ny * TILE          # (iw, ih)
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', choices=('cfg2', 'cfg3', 'cfg4'), default='cfg3')
     ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default='mx',
                     help='parity: bf16x2 split, 3 MFMA passes (logit error 3e-5); mx: fp16 pass + MX-fp4 cross terms '
                          '(5e-4, inside the 1e-3 contract); speed: single-pass bf16 (2e-2, outside the contract)')
     ap.add_argument('--batch', type=int, default=2000, help='tiles per trunk call (r01: 1000 -> 2000 +2.3 %, 5000 +3 %)')
-    ap.add_argument('--tiles', type=int, default=TILES_PER_GPU, help='tiles per GPU per step')
+    ap.add_argument('--tiles', type=int, default=10000, help='cfg2: tiles per GPU per step')
+    ap.add_argument('--size', type=int, default=40000, help='cfg3: slide edge in pixels')
+    ap.add_argument('--regions', type=int, default=4000, help='cfg4: region bags (16 crops of 64x64 each) in total')
     ap.add_argument('--chunks', type=str, default='', help='stem_chunk,layer1_chunk sub-batch sizes (default: library default)')
     ap.add_argument('--stem', type=str, default='', help='fused,rows_per_seg for the stem kernel (A/B)')
     ap.add_argument('--s2', type=int, default=-1, help='wsi_conv_set_mode value for A/B runs (see include/wsi_hip.h)')
     ap.add_argument('--streams', type=int, default=1, help='batches in flight (HIP streams); >1 distorts per-kernel timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='disable per-launch HIP events (roofline leg)')
-    args = ap.parse_args()
+    ap.add_argument('--no-bf16-leg', action='store_true', help='skip the single-pass bf16 timing of the dominant kernel')
+    return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """Parent of a plain `python bench.py --gpus N`: N fresh child processes, one per GPU, rendezvous on 127.0.0.1.
+    The parent makes no GPU call (nothing here imports torch); a failed child fails the run."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:                    # a dead rank leaves the others in the rendezvous: stop them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def slide_geometry_cfg2(n_tiles):
+    ny = (n_tiles + 1 + NX) // (NX + 1) - 1
+    while (NX + 1) * (ny + 1) - 1 < n_tiles:
+        ny += 1
+    return 257 + NX * TILE, 257 + ny * TILE          # (iw, ih)
+
+
+def collect_prof(lib, np, cap, dt):
+    ms = np.zeros(cap, np.float32)
+    kind = np.zeros(cap, np.int32)
+    fl = np.zeros(cap, np.float64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    nrec = lib.wsi_prof_end(p(ms), p(kind), p(fl), cap)
+    assert nrec >= 0
+    per_kind = {}
+    for k, name in KIND_NAMES.items():
+        sel = kind[:nrec] == k
+        if sel.any():
+            tms, tfl = float(ms[:nrec][sel].sum()), float(fl[:nrec][sel].sum())
+            per_kind[name] = {'launches': int(sel.sum()), 'avg_ms': tms / int(sel.sum()),
+                              'tflops': tfl / (tms * 1e-3) / 1e12, 'share_of_step': (tms * 1e-3 / dt) if dt else None}
+    return per_kind
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the inference path has no CPU fallback')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # "nccl" is RCCL on ROCm
 
     from wsi_segmentation_pipeline_amd import native, slide as S
     from wsi_segmentation_pipeline_amd.engine import TrunkEngine, PARITY, SPEED, MX
@@ -88,28 +152,6 @@ def main():
         native.check(lib.wsi_stem_set_mode(f, r), 'wsi_stem_set_mode')
     if args.s2 >= 0:
         native.check(lib.wsi_conv_set_mode(args.s2), 'wsi_conv_set_mode')
-    sd = W.make_resnet18_state_dict(11, with_fc=False)
-    cls = W.make_head_state_dict(22, 'classifier')
-    eng = TrunkEngine(sd, dev, planes=planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch,
-                      streams=args.streams)
-
-    total_tiles = args.tiles * world
-    iw, ih = slide_geometry(total_tiles)
-    g = torch.Generator(device=dev).manual_seed(3)
-    level0 = torch.empty((ih, iw, 3), dtype=torch.uint8, device=dev)             # same content on every rank
-    band = max(1, (1 << 30) // (iw * 3))                                         # <= 1 Gi elements per RNG call
-    for y0 in range(0, ih, band):
-        level0[y0:y0 + band] = torch.randint(0, 256, (min(band, ih - y0), iw, 3), dtype=torch.uint8, device=dev, generator=g)
-    tiles = S.tile_grid(iw, ih, TILE, TILE, TILE, TILE)[:total_tiles]
-    assert len(tiles) == total_tiles, (len(tiles), total_tiles)
-    m = 1.0 / 16.0                                       # downsample[0] / downsample[2]
-    map_hw = (ih // 16, iw // 16)
-    mask = torch.ones(map_hw, dtype=torch.uint8, device=dev)
-    class_probs = (0., 0., 0., 0.)
-
-    def step():
-        return S.infer_slide_cls(eng, level0, tiles, TILE, TILE, m, map_hw, 4, class_probs, mask, rank, world,
-                                 want_probs=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -117,11 +159,70 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ------------------------------------------------------------------------------- workload set-up
+    if args.workload == 'cfg4':
+        from wsi_segmentation_pipeline_amd import bags as B
+        sd = W.make_resnet18_state_dict(11, with_fc=True)
+        eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=args.batch * 16)
+        wl = B.BagWorkload(eng, sd, args.regions, seed=4, device=dev, rank=rank, world=world)
+        units_per_step = wl.total_crops
+        step = wl.step
+        unit, metric = 'crops/s', 'crops/sec (64x64x3, 16-crop region bags, ensemble head) region-proposal inference (BASELINE configs[3])'
+        workload_desc = ('cfg4: %d region bags x 16 crops of 64x64, ResNet-18 bag forward (fc0 per crop + fc 8192->4096->4 per bag), '
+                         'bags sharded by count over %d rank(s), ensemble logits gathered' % (args.regions, world))
+        scaling = 'strong'
+        parallelism = 'bag-shard x%d + 1 all-gather' % world
+        tiles_total = units_per_step
+    else:
+        sd = W.make_resnet18_state_dict(11, with_fc=False)
+        cls = W.make_head_state_dict(22, 'classifier')
+        eng = TrunkEngine(sd, dev, planes=planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch,
+                          streams=args.streams)
+        if args.workload == 'cfg3':
+            iw = ih = args.size
+            tiles = S.tile_grid(iw, ih, TILE, TILE, TILE, TILE)
+            total_tiles = len(tiles)
+            scaling = 'strong'
+        else:
+            total_tiles = args.tiles * world
+            iw, ih = slide_geometry_cfg2(total_tiles)
+            tiles = S.tile_grid(iw, ih, TILE, TILE, TILE, TILE)[:total_tiles]
+            assert len(tiles) == total_tiles, (len(tiles), total_tiles)
+            scaling = 'weak'
+        # this rank's share of the slide: only the rectangles its own tiles touch are generated and kept in HBM
+        lo, hi = S.shard_range(total_tiles, rank, world)
+        src = S.SyntheticRows(iw, ih, 3, dev)
+        rects, atlas_hw, local_xy = S.region_plan(tiles[lo:hi], TILE, TILE)
+        level0 = S.resident_regions(src, rects, atlas_hw, dev)
+        resident_gb = level0.numel() / 1e9
+        m = 1.0 / 16.0                                       # downsample[0] / downsample[2]
+        map_hw = (ih // 16, iw // 16)
+        mask = torch.ones(map_hw, dtype=torch.uint8, device=dev)
+        class_probs = (0., 0., 0., 0.)
+
+        def step():
+            return S.infer_slide_cls(eng, level0, tiles, TILE, TILE, m, map_hw, 4, class_probs, mask, rank, world,
+                                     want_probs=False, local_xy=local_xy)
+        units_per_step = total_tiles
+        unit, metric = 'patches/s', METRIC
+        if args.workload == 'cfg3':
+            workload_desc = ('cfg3: ONE %dx%d synthetic slide, tile 256 stride 256 -> %d tiles sharded over %d rank(s) (each holds '
+                             'only its own slide regions: %.2f GB on rank 0), ResNet-18 trunk + Classifier, fused read+normalise+conv HIP '
+                             'path, 1 all-gather, float64 stitch + softmax' % (iw, ih, total_tiles, world, resident_gb))
+        else:
+            workload_desc = ('cfg2: ResNet-18 trunk + Classifier, %d-tile slide per GPU, tile 256 stride 256, '
+                             'fused read+normalise+conv HIP path, float64 stitch + softmax' % args.tiles)
+        parallelism = 'tile-shard x%d + 1 all-gather' % world
+        tiles_total = total_tiles
+
+    # ------------------------------------------------------------------------------- timed region
     for _ in range(args.warmup):
         step()
     fence()
     prof_on = not args.no_prof
-    launches_per_step = (21 if not args.chunks else 200) * ((args.tiles + args.batch - 1) // args.batch)
+    per_rank_units = (units_per_step + world - 1) // world
+    nb = max(1, -(-per_rank_units // (args.batch * (16 if args.workload == 'cfg4' else 1))))
+    launches_per_step = (24 if not args.chunks else 200) * nb
     if prof_on and launches_per_step * args.steps <= 16384:
         native.check(lib.wsi_prof_begin(launches_per_step * args.steps), 'wsi_prof_begin')
     else:
@@ -131,78 +232,90 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    roofline = None
-    roofline_l1 = None
-    per_kind = {}
-    if prof_on:
-        cap = launches_per_step * args.steps
-        ms = np.zeros(cap, np.float32)
-        kind = np.zeros(cap, np.int32)
-        fl = np.zeros(cap, np.float64)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        nrec = lib.wsi_prof_end(p(ms), p(kind), p(fl), cap)
-        assert nrec >= 0
-        for k, name in KIND_NAMES.items():
-            sel = kind[:nrec] == k
-            if sel.any():
-                tms, tfl = float(ms[:nrec][sel].sum()), float(fl[:nrec][sel].sum())
-                per_kind[name] = {'launches': int(sel.sum()), 'avg_ms': tms / int(sel.sum()),
-                                  'tflops': tfl / (tms * 1e-3) / 1e12, 'share_of_step': tms * 1e-3 / dt}
-        # Dominant kernel = the stride-1 3x3 conv of layers 2-4 (9 launches per batch; with the wide kernel of the split modes
-        # ~41 % of the step).  The 64-channel layer 1 runs a different kernel and is HBM-bound: reported beside it.
-        tj = None
-        tpath = os.path.join(ROOT, 'profiles', {2: 'r01_traffic.json', 3: 'r01_traffic_mx.json'}.get(planes, 'none'))
-        if os.path.exists(tpath):
-            # HBM bytes per launch from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE,
-            # collected at batch 1000); scaled to this run's batch
-            tj = json.load(open(tpath))
-
-        def pmc_bytes(substr):
-            if not tj:
-                return None
-            sel = [v for k, v in tj['kernels'].items() if substr in k]
-            if not sel:
-                return None
-            return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / sum(v['launches'] for v in sel) * args.batch / 1000.0)
-        if 'conv3x3_s1' in per_kind:
-            k = per_kind['conv3x3_s1']
-            wide = planes >= 2
-            roofline = {'kernel': ('conv3x3s1_wide_kernel' if wide else 'conv3x3s1_slab3_kernel') +
-                                  ' (9 launches per batch: the stride-1 3x3 convs of layers 2-4)',
-                        'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(k['tflops'] / PEAK_BF16_TFLOPS, 4),
-                        'traffic': pmc_bytes('conv3x3s1_wide' if wide else 'conv3x3s1_slab3_kernel<4, 1, 4'),
-                        'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)' % os.path.basename(tpath),
-                        'avg_launch_ms': round(k['avg_ms'], 4),
-                        'mfma_passes': {2: '6 bf16 K=16 per 32-channel step', 3: '2 fp16 K=16 + 1 MX-fp4 K=64 per 32-channel step',
-                                        1: '2 bf16 K=16 per 32-channel step'}[planes]}
-        if 'conv3x3_s1_layer1' in per_kind:
-            k = per_kind['conv3x3_s1_layer1']
-            # algorithmic bytes per launch: input + output (+ residual on every second launch) of a (batch, 64, 64, 64) tensor
-            bpc = 2 if planes == 1 else 4
-            tensor = args.batch * 64 * 64 * 64 * bpc
-            alg = 2.5 * tensor
-            gbs = alg / (k['avg_ms'] * 1e-3) / 1e9
-            roofline_l1 = {'kernel': 'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)', 'bound': 'hbm',
-                           'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                           'traffic': pmc_bytes('conv3x3s1_slab3_kernel<4, 2, 2'), 'algorithmic_bytes_per_launch': round(alg),
-                           'avg_launch_ms': round(k['avg_ms'], 4), 'tflops': round(k['tflops'], 2)}
+    per_kind = collect_prof(lib, np, launches_per_step * args.steps, dt) if prof_on else {}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    value = total_tiles * args.steps / dt
+    value = units_per_step * args.steps / dt
 
+    # ------------------------------------------------------------------------------- roofline objects (rank 0's kernels)
+    eff_batch = -(-per_rank_units // nb) if args.workload != 'cfg4' else None
+    roofline = roofline_l1 = roofline_bf16 = None
+    prof_tag = os.environ.get('WSI_TRAFFIC_JSON', '')
+    tj = None
+    for cand in ([prof_tag] if prof_tag else []) + [os.path.join(ROOT, 'profiles', f) for f in
+                                                    ({3: ['r02_traffic_mx.json', 'r01_traffic_mx.json'], 2: ['r02_traffic.json', 'r01_traffic.json']}.get(planes, []))]:
+        if cand and os.path.exists(cand):
+            tj, tpath = json.load(open(cand)), cand
+            break
+
+    def pmc_bytes(substr, batch):
+        # HBM bytes per launch from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE,
+        # collected at batch 1000), scaled to this run's batch
+        if not tj or batch is None:
+            return None
+        sel = [v for k, v in tj['kernels'].items() if substr in k]
+        if not sel:
+            return None
+        return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / sum(v['launches'] for v in sel) * batch / 1000.0)
+
+    passes = {2: '6 bf16 K=16 per 32-channel step', 3: '2 fp16 K=16 + 1 MX-fp4 K=64 per 32-channel step', 1: '2 bf16 K=16 per 32-channel step'}
+    if 'conv3x3_s1' in per_kind:
+        k = per_kind['conv3x3_s1']
+        # Dominant kernel = the stride-1 3x3 conv of layers 2-4 (9 launches per batch); algorithmic FLOPs = 2*M*N*K over
+        # real output pixels (302 MFLOP per conv and 256x256 patch); split passes are not counted
+        roofline = {'kernel': 'conv3x3s1_wide_kernel (9 launches per batch: the stride-1 3x3 convs of layers 2-4)',
+                    'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(k['tflops'] / PEAK_BF16_TFLOPS, 4),
+                    'traffic': pmc_bytes('conv3x3s1_wide', eff_batch),
+                    'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)' % (os.path.relpath(tpath, ROOT) if tj else 'not collected'),
+                    'avg_launch_ms': round(k['avg_ms'], 4), 'mfma_passes': passes[planes], 'precision_mode': args.mode}
+    l1 = per_kind.get('layer1_block_fused') or per_kind.get('conv3x3_s1_layer1')
+    if l1 and eff_batch:
+        fusedk = 'layer1_block_fused' in per_kind
+        bpc = 2 if planes == 1 else 4
+        tensor = eff_batch * 64 * 64 * 64 * bpc
+        # algorithmic bytes per launch: unfused conv = input + output (+ residual on every second launch) = 2.5 tensors on
+        # average; fused BasicBlock = input + output (the residual is the input, the intermediate never leaves the CU)
+        alg = (2.0 if fusedk else 2.5) * tensor
+        gbs = alg / (l1['avg_ms'] * 1e-3) / 1e9
+        roofline_l1 = {'kernel': ('layer1_block_kernel (2 launches per batch: one fused 64-channel BasicBlock each)' if fusedk else
+                                  'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)'), 'bound': 'hbm',
+                       'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                       'traffic': pmc_bytes('layer1_block' if fusedk else 'conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
+                       'algorithmic_bytes_per_launch': round(alg), 'avg_launch_ms': round(l1['avg_ms'], 4), 'tflops': round(l1['tflops'], 2)}
+
+    # the same dominant kernel in single-pass bf16 (the literal dtype of BASELINE configs[1]; logit error ~2e-2, outside the
+    # contract, so never the headline): one profiled pass on rank 0, outside the timed region
+    if rank == 0 and prof_on and not args.no_bf16_leg and planes != SPEED and args.workload != 'cfg4':
+        eng1 = TrunkEngine(sd, dev, planes=SPEED, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch)
+        nsub = min(hi - lo, 2 * args.batch)
+        sub = torch.from_numpy(np.ascontiguousarray(local_xy[:nsub])).to(dev)
+        eng1.forward_tiles(level0, sub, TILE, TILE, logits=True)
+        torch.cuda.synchronize()
+        native.check(lib.wsi_prof_begin(256), 'wsi_prof_begin')
+        for _ in range(3):
+            eng1.forward_tiles(level0, sub, TILE, TILE, logits=True)
+        torch.cuda.synchronize()
+        k1 = collect_prof(lib, np, 256, 0.0).get('conv3x3_s1')
+        if k1:
+            roofline_bf16 = {'kernel': 'stride-1 3x3 conv of layers 2-4, single-pass bf16 (precision mode "speed")', 'bound': 'mfma',
+                             'achieved': round(k1['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': round(k1['tflops'] / PEAK_BF16_TFLOPS, 4), 'avg_launch_ms': round(k1['avg_ms'], 4),
+                             'batch': -(-nsub // max(1, -(-nsub // args.batch))), 'timed': 'outside the timed region (3 passes over %d tiles)' % nsub}
+        del eng1
+
+    # ------------------------------------------------------------------------------- CPU baseline (rank 0, N = 1)
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import resnet_oracle as R
-        nsample = 128                                    # ~1.3 s per pass at ~100 patches/s: 2 thread settings x (1 + 3) passes = 10-15 s
-        xy = tiles[:nsample]
-        u8 = torch.stack([level0[y:y + TILE, x:x + TILE] for x, y in xy]).permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != 'cfg4':
+        from oracle import resnet_oracle as R                 # the checker, never the thing measured above
         avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        best = None
+        res = {}
         with torch.no_grad():
-            for cores in sorted({min(16, avail), avail}):        # the GPU box's CPU share is 16 cores per GPU
+            for cores, nsample in ((1, 32), (min(16, avail), 128)):        # ~1.6 s and ~1.5 s per pass: 4 passes each
+                lxy = local_xy[:nsample]                                       # the same first tiles, read from the resident atlas
+                u8 = torch.stack([level0[y:y + TILE, x:x + TILE] for x, y in lxy]).permute(0, 3, 1, 2).contiguous().cpu().numpy()
                 torch.set_num_threads(cores)
                 ref = R.tile_logits(sd, cls, u8)                               # warm-up (also the sanity reference)
                 ts = []
@@ -210,31 +323,42 @@ def main():
                     c0 = time.perf_counter()
                     R.tile_logits(sd, cls, u8)
                     ts.append(time.perf_counter() - c0)
-                if best is None or float(np.median(ts)) < best[0]:
-                    best = (float(np.median(ts)), cores)
-        ts, cores = [best[0]], best[1]
-        got = out['logits'][:nsample].cpu()
-        cpu_baseline = {'value': round(nsample / float(np.median(ts)), 2), 'unit': 'patches/s', 'cores': cores,
-                        'kind': 'port', 'sample': 'first %d tiles of the same slide, fp32 torch CPU oracle, median of 3, best of 16 / all host threads' % nsample,
-                        'max_abs_logit_diff_vs_gpu': float((got - ref).abs().max())}
+                res[cores] = (nsample / float(np.median(ts)), nsample, ref)
+        many = max(res)
+        got = out['logits'][:res[many][1]].cpu()
+        cpu_baseline = {'value': round(res[many][0], 2), 'unit': 'patches/s', 'cores': many, 'kind': 'port',
+                        'sample': 'first %d tiles of the same slide, fp32 torch CPU oracle (oracle/resnet_oracle.py), 1 warm-up + median of 3' % res[many][1],
+                        'single_thread': {'value': round(res[1][0], 2), 'cores': 1, 'sample': 'first %d tiles' % res[1][1]},
+                        'host_threads_available': avail,
+                        'max_abs_logit_diff_vs_gpu': float((got - res[many][2]).abs().max())}
 
     if rank == 0:
         line = {
-            'metric': METRIC, 'value': round(value, 1), 'unit': 'patches/s',
+            'metric': metric, 'value': round(value, 1), 'unit': unit,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': {2: 'bf16x2-split (3 MFMA passes, fp32 accumulate)', 3: 'fp16 + MX-fp4 cross terms (fp32 accumulate)',
                       1: 'bf16 (fp32 accumulate)'}[planes],
             'data': 'synthetic (seeded u8 slide resident in HBM, seeded random ResNet-18 weights)',
-            'config': {'workload': 'cfg2: ResNet-18 trunk + Classifier, %d-tile slide per GPU, tile 256 stride 256, '
-                                   'fused read+normalise+conv HIP path, float64 stitch + softmax' % args.tiles,
-                       'tiles_total': total_tiles, 'batch': args.batch, 'mode': args.mode,
-                       'parallelism': 'tile-shard x%d + 1 all-gather' % world},
-            'roofline': roofline, 'roofline_layer1': roofline_l1, 'cpu_baseline': cpu_baseline, 'kernels': per_kind,
+            'config': {'workload': workload_desc, 'tiles_total': tiles_total, 'batch': args.batch, 'mode': args.mode,
+                       'parallelism': parallelism},
+            'roofline': roofline, 'roofline_layer1': roofline_l1, 'roofline_bf16': roofline_bf16, 'cpu_baseline': cpu_baseline,
+            'kernels': per_kind,
         }
-        print(json.dumps(line))
+        if args.workload == 'cfg4':
+            line['roofline'] = wl.roofline(per_kind)
+            line['roofline_layer1'] = None
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    run_rank(args)
 
 
 if __name__ == '__main__':

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WSI_HIP_ABI_VERSION 1
+#define WSI_HIP_ABI_VERSION 2
 int wsi_hip_abi_version(void);
 
 /* ---- padded-flat layout helpers (host) -------------------------------------------------------
@@ -143,9 +143,11 @@ typedef struct {
 size_t wsi_trunk_workspace_bytes(int n, int h, int w, int planes);
 /* zero-fills the workspace for the (n,h,w,planes) plan; call once before the first forward */
 int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, void* stream);
+/* workspace_n: the image count the workspace was sized and initialised for (>= n; 0 means n): one workspace planned
+ * for the largest batch serves every smaller one (ragged last batches, variable bag counts) without re-initialisation. */
 int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
                       long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                      int n, int h, int w, void* workspace, float* feat_out /* [n][512] or NULL */,
+                      int n, int h, int w, void* workspace, int workspace_n, float* feat_out /* [n][512] or NULL */,
                       float* logits_out /* [n][head_k] or NULL */, float* fmap_out /* f32 NCHW [n][512][h/32][w/32] or NULL */,
                       void* stream);
 /* Sub-batching of the early (large-map) stages so their tensors stay in the 256 MiB Infinity Cache:
@@ -156,7 +158,8 @@ int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk);
  * layer1.0, layer1.1, ..., layer4.1) and unpack that tensor to f32 NCHW. */
 int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
                           long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                          int n, int h, int w, void* workspace, int stop_after, float* tap_out_nchw, void* stream);
+                          int n, int h, int w, void* workspace, int workspace_n, int stop_after, float* tap_out_nchw,
+                          void* stream);
 
 /* ---- measurement hook -------------------------------------------------------------------------
  * wsi_prof_begin arms HIP-event timing (on the launch stream) of every conv / stem launch made by

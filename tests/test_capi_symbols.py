@@ -92,4 +92,4 @@ def test_bad_arguments_return_einval(lib):
     assert lib.wsi_prepack_conv_bytes(48, 64, 3, 2) == 0
     assert lib.wsi_prepack_conv(None, None, None, None, None, 1e-5, 64, 64, 3, 2, None, None) == -22
     assert lib.wsi_conv3x3_bn_act(None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, 2, None) == -22
-    assert lib.wsi_trunk_forward(None, None, None, 0, 0, 0, None, None, 1, 64, 64, None, None, None, None, None) == -22
+    assert lib.wsi_trunk_forward(None, None, None, 0, 0, 0, None, None, 1, 64, 64, None, 0, None, None, None, None) == -22

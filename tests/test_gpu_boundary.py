@@ -126,9 +126,18 @@ def test_predict_tumorbed_cls_matches_oracle(dev, sd_full, tmp_path, stride):
             model = plain.cuda()
         res = val.predict_tumorbed(model, dataset, 7, mode='cls')['synthetic.svs']
         assert np.abs(res['logits'].cpu().numpy() - ref_logits).max() <= LOGIT_TOL
+        # (a) against the all-oracle pipeline the heat map inherits the <= 1e-3 logit differences: at most one LSB
         diff = np.abs(res['heatmap'].astype(int) - ref_heat.astype(int))
         assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
         assert (res['classes'] != ref_cls).mean() < 0.01
+        # (b) the slide-side stages themselves are bit-exact: the oracle stitch / threshold / heat map fed with the
+        #     GPU's OWN logits must reproduce the device map, classes and u8 heat map with ZERO differing pixels
+        own_pred = WO.stitch_tumorbed(tiles, res['logits'].cpu().numpy(), 4, mask.shape, m, 64, 64)
+        own_cls, own_probs = WO.threshold_probs(own_pred)
+        own_heat = WO.tumorbed_heatmap(own_probs, mask, 'cls')
+        n_cls, n_heat = int((res['classes'] != own_cls).sum()), int((res['heatmap'] != own_heat).sum())
+        print('stride %d fused %s: %d class / %d heat pixels differ of %d' % (stride, fused, n_cls, n_heat, own_cls.size))
+        assert n_cls == 0 and n_heat == 0
         assert os.path.exists('%s/7/synthetic.svs_%d_heatmap.png' % (a.val_save_pth, stride))
         assert os.path.exists('%s/7/synthetic.svs_%d_overlay.png' % (a.val_save_pth, stride))
         assert dataset.wsis['synthetic.svs'] is None

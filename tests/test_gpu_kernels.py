@@ -170,10 +170,14 @@ def test_tile_gather_stitch_softmax(dev):
     for th in ((0., 0., 0., 0.), (0.1, 0.3, 0.2, 0.25)):
         rc, rp = WO.threshold_probs(ref, th)
         cls, probs, heat = E.softmax_threshold_argmax(pred, th, torch.from_numpy(mask), 'cls')
-        assert np.abs(probs.cpu().numpy() - rp).max() <= 1e-12
-        assert (cls.cpu().numpy() != rc).mean() <= 1e-3           # ties under 1-ulp exp differences only
+        # probabilities: device f64 exp vs torch-CPU f64 exp may differ in the last bits (neither is correctly rounded)
+        assert np.abs(probs.cpu().numpy() - rp).max() <= 4 * np.finfo(np.float64).eps
+        # byte / index outputs are held to bit-exact: the COUNT of differing pixels is printed and must be 0
         rh = WO.tumorbed_heatmap(rp, mask, 'cls')
-        assert np.abs(heat.cpu().numpy().astype(int) - rh.astype(int)).max() <= 1
+        n_cls = int((cls.cpu().numpy() != rc).sum())
+        n_heat = int((heat.cpu().numpy() != rh).sum())
+        print('thresholds %s: %d class pixels, %d heat pixels differ of %d' % (th, n_cls, n_heat, rc.size))
+        assert n_cls == 0 and n_heat == 0
 
 
 @pytest.mark.parametrize('shape', [(3, 64, 128, 16, 16), (2, 64, 128, 64, 64), (3, 128, 256, 32, 32), (5, 256, 512, 16, 16), (7, 256, 512, 4, 4)])

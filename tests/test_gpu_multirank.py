@@ -22,37 +22,47 @@ def _free_port():
     return p
 
 
-def _pipeline(rank, world):
+def _pipeline(rank, world, resident=False):
     from wsi_segmentation_pipeline_amd import slide as S, synthetic as W
     from wsi_segmentation_pipeline_amd.engine import TrunkEngine
     dev = torch.device('cuda:0')
     sd = W.make_resnet18_state_dict(11, with_fc=False)
     cls = W.make_head_state_dict(22, 'classifier')
-    rng = np.random.default_rng(5)
-    level0 = torch.from_numpy(rng.integers(0, 256, (530, 790, 3), dtype=np.uint8)).to(dev)
+    src = S.SyntheticRows(790, 530, 5, dev, block=64)
     tiles = S.tile_grid(790, 530, 64, 64, 48, 48)                       # overlapping tiles: 159 of them
     eng = TrunkEngine(sd, dev, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=64)
-    out = S.infer_slide_cls(eng, level0, tiles, 64, 64, 0.25, (132, 197), 4, (0., 0., 0., 0.), None, rank, world)
+    if resident:                                                        # bench.py's cfg3 path: only this rank's slide regions exist
+        lo, hi = S.shard_range(len(tiles), rank, world)
+        rects, hw, local_xy = S.region_plan(tiles[lo:hi], 64, 64)
+        level0 = S.resident_regions(src, rects, hw, dev)
+        assert level0.numel() < 0.8 * 790 * 530 * 3 or world == 1
+    else:
+        level0, local_xy = src.full(), None
+    out = S.infer_slide_cls(eng, level0, tiles, 64, 64, 0.25, (132, 197), 4, (0., 0., 0., 0.), None, rank, world,
+                            local_xy=local_xy)
     torch.cuda.synchronize()
     return {k: v.cpu() for k, v in out.items() if v is not None}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, resident):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _pipeline(rank, world)
+    res = _pipeline(rank, world, resident)
     q.put((rank, {k: v.numpy() for k, v in res.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_pipeline_equals_single_rank():
+@pytest.mark.parametrize('resident', [False, True])
+def test_two_rank_pipeline_equals_single_rank(resident):
+    """resident=True: every rank holds only the slide regions of its own tiles (the band-resident path of bench.py
+    cfg3) and must still reproduce the single-rank, whole-slide result bit for bit."""
     ref = _pipeline(0, 1)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, resident)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in procs)

@@ -220,3 +220,30 @@ def test_forward_is_bit_deterministic(dev, sd):
         assert bool(torch.isfinite(ref).all())
         for _ in range(6):
             assert torch.equal(ref, eng.forward_tiles(slide, xy, 256, 256, logits=True)[1])
+
+
+@pytest.mark.parametrize('planes', [1, 2, 3])
+def test_trunk_set_chunks_equals_unchunked(dev, sd, planes):
+    """wsi_trunk_set_chunks (sub-batches of the stem / layer-1 stages) must not change a single bit in any precision
+    mode (r01 bug: the per-image offset used 6 B/channel for the mx format, which has 4)."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    u8 = W.make_u8_patches(21, (1, 7, 3, 64, 64)).reshape(-1, 3, 64, 64)
+    strip = np.ascontiguousarray(u8.transpose(0, 2, 3, 1).reshape(-1, 64, 3))
+    xy = np.stack((np.zeros(7, np.int32), np.arange(7, dtype=np.int32) * 64), 1)
+    sl, xyd = torch.from_numpy(strip).to(dev), torch.from_numpy(xy).to(dev)
+    eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']))
+    x = R.normalize_u8(u8).to(dev)
+    base_t = [t.clone() for t in eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=True, fmap=True)]
+    base_f = [t.clone() for t in eng.forward_f32(x, feat=True, logits=True, fmap=True)]
+    try:
+        for cs, c1 in ((2, 4), (1, 1), (3, 0), (0, 2)):
+            native.check(lib.wsi_trunk_set_chunks(cs, c1), 'wsi_trunk_set_chunks')
+            got_t = eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=True, fmap=True)
+            got_f = eng.forward_f32(x, feat=True, logits=True, fmap=True)
+            for a, b in zip(list(got_t) + list(got_f), base_t + base_f):
+                assert torch.equal(a, b), (planes, cs, c1)
+    finally:
+        lib.wsi_trunk_set_chunks(0, 0)
+    assert lib.wsi_trunk_set_chunks(2, 3) != 0                    # layer1 chunk must be a multiple of the stem chunk

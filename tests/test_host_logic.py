@@ -94,3 +94,101 @@ def test_gather_tile_logits_gloo_world2(total):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------ rank-resident slide regions
+@pytest.mark.parametrize('grid', [(64, 64, 64, 64), (64, 64, 48, 40), (128, 64, 100, 30)])
+def test_region_plan_atlas_equals_full_slide(grid):
+    """Every tile read from a rank's atlas (only the rectangles its own tiles touch) == the same tile read from the
+    whole slide, for every rank of every world size; the atlases together stay close to ONE copy of the slide."""
+    ph, pw, sh, sw = grid
+    src = S.SyntheticRows(1000, 700, 5, 'cpu', block=64)
+    full = src.full()
+    tl = S.tile_grid(1000, 700, ph, pw, sh, sw)
+    for world in (1, 2, 3, 8):
+        total = 0
+        for r in range(world):
+            lo, hi = S.shard_range(len(tl), r, world)
+            rects, hw, loc = S.region_plan(tl[lo:hi], pw, ph)
+            at = S.resident_regions(src, rects, hw, 'cpu')
+            total += at.numel()
+            for (x, y), (lx, ly) in zip(tl[lo:hi], loc):
+                assert torch.equal(at[ly:ly + ph, lx:lx + pw], full[y:y + ph, x:x + pw])
+        assert total <= 1.6 * full.numel() + world * 3 * ph * 1000 * 2          # bands + a shelf or two per rank
+    rects, hw, loc = S.region_plan(np.zeros((0, 2), np.int32), pw, ph)           # a rank without tiles
+    assert rects == [] and len(loc) == 0
+
+
+def test_region_plan_cfg3_footprint():
+    """cfg3 (40 000^2, 24 648 tiles): at 8 ranks every rank keeps ~0.6 GB of the 4.8 GB slide, the last one included
+    (its 138 right-edge tiles are shelf-packed, not kept as a 35 000-row strip)."""
+    tl = S.tile_grid(40000, 40000, 256, 256, 256, 256)
+    sizes = []
+    for r in range(8):
+        lo, hi = S.shard_range(len(tl), r, 8)
+        rects, hw, loc = S.region_plan(tl[lo:hi], 256, 256)
+        assert loc.min() >= 0 and loc[:, 0].max() + 256 <= hw[1] and loc[:, 1].max() + 256 <= hw[0]
+        sizes.append(hw[0] * hw[1] * 3)
+    assert max(sizes) < 0.7e9 and sum(sizes) < 1.06 * 4.8e9
+
+
+def _tile_features(buf, xy, ph, pw):
+    # exact per-tile integers (channel sums) + the corner sample: any wrong crop changes them
+    return torch.stack([torch.cat([buf[y:y + ph, x:x + pw].to(torch.int64).sum((0, 1)).float() / 64.0,
+                                   buf[y, x, :1].float()]) for x, y in xy]) if len(xy) else torch.zeros((0, 4))
+
+
+def _resident_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    src = S.SyntheticRows(1000, 700, 9, 'cpu', block=64)
+    tl = S.tile_grid(1000, 700, 64, 64, 48, 40)
+    lo, hi = S.shard_range(len(tl), rank, world)
+    rects, hw, loc = S.region_plan(tl[lo:hi], 64, 64)
+    atlas = S.resident_regions(src, rects, hw, 'cpu')                        # this rank never builds the whole slide
+    out = S.gather_tile_logits(_tile_features(atlas, loc, 64, 64), len(tl), rank, world)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resident_shards_gathered_equal_full_slide_gloo_world2():
+    """The N>1 data path of bench.py's cfg3: shard -> each rank's resident regions -> per-tile values -> ONE
+    all-gather; both ranks must end with exactly what one rank computes from the whole slide."""
+    src = S.SyntheticRows(1000, 700, 9, 'cpu', block=64)
+    tl = S.tile_grid(1000, 700, 64, 64, 48, 40)
+    ref = _tile_features(src.full(), tl, 64, 64).numpy()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resident_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the parent starts N child processes with the rendezvous
+    environment and fails when a child fails (no GPU needed: the children are stubbed by a tiny script)."""
+    import bench
+    import sys as _sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        stub = os.path.join(d, 'stub.py')
+        with open(stub, 'w') as f:
+            f.write('import os, sys\n'
+                    'r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])\n'
+                    'assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0\n'
+                    'assert int(os.environ["LOCAL_RANK"]) == r and w == 3\n'
+                    'open(os.path.join(os.path.dirname(__file__), "rank%d" % r), "w").write("x")\n'
+                    'sys.exit(int(os.environ.get("STUB_FAIL", "-1")) == r)\n')
+        monkeypatch.setattr(bench, '__file__', stub)
+        monkeypatch.setattr(_sys, 'argv', ['bench.py', '--gpus', '3'])
+        assert bench.spawn_ranks(3) == 0
+        assert sorted(f for f in os.listdir(d) if f.startswith('rank')) == ['rank0', 'rank1', 'rank2']
+        monkeypatch.setenv('STUB_FAIL', '1')
+        assert bench.spawn_ranks(3) != 0

@@ -296,7 +296,7 @@ static int g_s2_split = 1;                            // trunk: phase-split stag
 
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
-                       int cfg = -1, int split_out = 0) {
+                       int cfg = -1, int split_out = 0, long long split_pixels = 0) {
     if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
     if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
     ConvArgs a;
@@ -306,7 +306,8 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.stride = stride; a.ksize = ksize; a.relu = relu;
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
     a.in_split_pixels = 0;
-    a.out_split_pixels = split_out ? pf_alloc_pixels(n, h_in / 2, w_in / 2) : 0;
+    // distance between the four phase images: the caller's (a workspace planned for more images) or the tight one
+    a.out_split_pixels = split_out ? (split_pixels ? split_pixels : pf_alloc_pixels(n, h_in / 2, w_in / 2)) : 0;
     if (split_out && (stride != 1 || ksize != 3 || h_in % 2 || w_in % 2 || planes < 2)) return WSI_EINVAL;
     if (ksize == 3 && stride == 2 && cout % 128 == 0 && cfg != 0 && g_s2_slab) {
         const int rc = wsi_s2_dispatch(a, planes, (hipStream_t)stream);
@@ -331,9 +332,19 @@ int wsi_conv3x3_bn_act_split(const void* in_pf, void* out_split, const void* res
     return conv_common(in_pf, out_split, resid_pf, wpk, bias, n, h, w, cin, cout, 1, 3, relu, planes, stream, -1, 1);
 }
 
+static int s2_split_common(const void* in_split, void* out_conv_pf, void* out_ds_pf, const void* wpk3,
+                           const float* bias3, const void* wpk1, const float* bias1, int n, int h_in, int w_in,
+                           int cin, int cout, int planes, void* stream, long long split_pixels);
+
 int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* out_ds_pf, const void* wpk3,
                                  const float* bias3, const void* wpk1, const float* bias1, int n, int h_in, int w_in,
                                  int cin, int cout, int planes, void* stream) {
+    return s2_split_common(in_split, out_conv_pf, out_ds_pf, wpk3, bias3, wpk1, bias1, n, h_in, w_in, cin, cout, planes, stream, 0);
+}
+
+static int s2_split_common(const void* in_split, void* out_conv_pf, void* out_ds_pf, const void* wpk3,
+                           const float* bias3, const void* wpk1, const float* bias1, int n, int h_in, int w_in,
+                           int cin, int cout, int planes, void* stream, long long split_pixels) {
     if (!in_split || !out_conv_pf || !out_ds_pf || !wpk3 || !bias3 || !wpk1 || !bias1 || n <= 0 || h_in % 2 || w_in % 2)
         return WSI_EINVAL;
     if (in_split == out_conv_pf || in_split == out_ds_pf || out_conv_pf == out_ds_pf) return WSI_EINVAL;
@@ -344,7 +355,7 @@ int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* 
     a.stride = 2; a.ksize = 3; a.relu = 1;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
     a.out_split_pixels = 0;
-    a.in_split_pixels = pf_alloc_pixels(n, h_in / 2, w_in / 2);
+    a.in_split_pixels = split_pixels ? split_pixels : pf_alloc_pixels(n, h_in / 2, w_in / 2);
     return wsi_s2_dispatch(a, planes, (hipStream_t)stream);      // EINVAL outside the wide kernel's range (output maps wider than 33)
 }
 
@@ -531,8 +542,12 @@ int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, v
 
 // Runs stem + residual stages; stops after stage `stop_after` (0 = pool, 1..8 = blocks, >= 8 all).
 // Returns the workspace offset / geometry of the last tensor produced.
+// `p` is the plan of the workspace, made for `cap` >= n images: buffer offsets and the distance between phase images
+// come from the plan, so one workspace serves every batch size up to cap (image i sits at the same place whatever n is;
+// what images >= n still hold from an earlier, larger batch is never read: the zero row / column that close image
+// n-1 belong to its own block).
 static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide, long long pitch, int slide_h,
-                     int slide_w, const int* tile_xy, const float* lut, int n, int h, int w, void* workspace,
+                     int slide_w, const int* tile_xy, const float* lut, int n, int cap, int h, int w, void* workspace,
                      int stop_after, hipStream_t st, const TrunkPlan& p, size_t& last_off, int& last_stage) {
     char* ws = (char*)workspace;
     const int planes = wt->planes;
@@ -548,7 +563,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
         if (rc) return rc;                                                                          \
     } while (0)
     // byte offset of image n0 inside a PF buffer of stage s
-    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * planes * 2; };
+    const size_t bpc = planes == 1 ? PFmt<1>::BPC : PFmt<2>::BPC;     // bytes per channel: 2 (speed) or 4 (parity, mx)
+    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * bpc; };
 
     // ---- stem + maxpool + layer1 run in sub-batches so that the 4 MB/patch fp32 stem scratch and
     //      the 1 MB/patch layer-1 tensors stay resident in the 256 MiB Infinity Cache; the deeper
@@ -583,8 +599,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
                                                                      H1, W1, 64, 64, 1, 1, planes, st));
             if (b == 1 && split0) {                    // layer1's output feeds only the stride-2 entry of layer2
-                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act_split(mid, ws + p.buf[0][3], x, wt->conv_w[3], wt->conv_b[3],
-                                                                               nn1, H1, W1, 64, 64, 1, planes, st));
+                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, ws + p.buf[0][3], x, wt->conv_w[3], wt->conv_b[3], nn1, H1, W1, 64,
+                                                                  64, 1, 3, 1, planes, st, -1, 1, pf_alloc_pixels(cap, H1 / 2, W1 / 2)));
             } else {
                 PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
                                                                          nn1, H1, W1, 64, 64, 1, 1, planes, st));
@@ -612,8 +628,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 out = ws + p.buf[s][0];
                 if (g_s2_slab) {
                     const int pi_ = prof_open(st, 2, 2.0 * n * H * W * (double)C * (C / 2) * 10);
-                    rc = x_split ? wsi_conv3x3s2_ds_fused_split(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1],
-                                                                wt->down_b[s - 1], n, 2 * H, 2 * W, C / 2, C, planes, st)
+                    rc = x_split ? s2_split_common(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1],
+                                                   wt->down_b[s - 1], n, 2 * H, 2 * W, C / 2, C, planes, st, pf_alloc_pixels(cap, H, W))
                                  : wsi_conv3x3s2_ds_fused(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1], wt->down_b[s - 1], n,
                                                           2 * H, 2 * W, C / 2, C, planes, st);
                     prof_close(st, pi_);
@@ -639,8 +655,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             }
             if (b == 1 && can_split(s)) {              // the stage's output feeds only the next stage's stride-2 entry
                 out = ws + p.buf[s][3];
-                PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act_split(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W,
-                                                                         C, C, 1, planes, st));
+                PROF_CONV(1, n, H, W, C, C, 9, conv_common(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C, C, 1, 3, 1,
+                                                            planes, st, -1, 1, pf_alloc_pixels(cap, H / 2, W / 2)));
                 x_split = true;
             } else {
                 PROF_CONV(1, n, H, W, C, C, 9, wsi_conv3x3_bn_act(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C,
@@ -658,13 +674,14 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
 
 int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
                       long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                      int n, int h, int w, void* workspace, float* feat_out, float* logits_out, float* fmap_out,
-                      void* stream) {
+                      int n, int h, int w, void* workspace, int workspace_n, float* feat_out, float* logits_out,
+                      float* fmap_out, void* stream) {
     TrunkPlan p;
-    if (!wt || !workspace || trunk_plan(n, h, w, wt->planes, p)) return WSI_EINVAL;
+    const int cap = workspace_n > 0 ? workspace_n : n;
+    if (!wt || !workspace || n <= 0 || cap < n || trunk_plan(cap, h, w, wt->planes, p)) return WSI_EINVAL;
     if (logits_out && (!wt->head_w || !wt->head_b || wt->head_k <= 0)) return WSI_EINVAL;
     size_t off; int stage;
-    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, h, w, workspace, 8,
+    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, cap, h, w, workspace, 8,
                        (hipStream_t)stream, p, off, stage);
     if (rc) return rc;
     const char* last = (const char*)workspace + off;
@@ -679,12 +696,15 @@ int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const ui
 
 int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,
                           long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                          int n, int h, int w, void* workspace, int stop_after, float* tap_out_nchw, void* stream) {
+                          int n, int h, int w, void* workspace, int workspace_n, int stop_after, float* tap_out_nchw,
+                          void* stream) {
     TrunkPlan p;
-    if (!wt || !workspace || !tap_out_nchw || stop_after < 0 || stop_after > 8 || trunk_plan(n, h, w, wt->planes, p))
+    const int cap = workspace_n > 0 ? workspace_n : n;
+    if (!wt || !workspace || !tap_out_nchw || stop_after < 0 || stop_after > 8 || n <= 0 || cap < n ||
+        trunk_plan(cap, h, w, wt->planes, p))
         return WSI_EINVAL;
     size_t off; int stage;
-    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, h, w, workspace,
+    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, cap, h, w, workspace,
                        stop_after, (hipStream_t)stream, p, off, stage);
     if (rc) return rc;
     return wsi_pf_unpack((const char*)workspace + off, tap_out_nchw, n, p.sc[stage], p.sh[stage], p.sw[stage], wt->planes,

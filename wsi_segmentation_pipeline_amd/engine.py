@@ -141,23 +141,27 @@ class TrunkEngine:
         self.head_k = int(w.shape[0])
 
     def _workspace(self, n, h, w, slot=0):
-        key = (n, h, w, slot)
-        ws = self._ws.get(key)
-        if ws is None:
+        """(workspace, capacity): one workspace per (patch shape, stream slot), planned for the largest batch seen so far; it
+        serves every smaller batch as is (wsi_trunk_forward's workspace_n), so ragged last batches and variable bag
+        counts neither allocate nor re-zero ~8 MB per patch."""
+        key = (h, w, slot)
+        ent = self._ws.get(key)
+        if ent is None or ent[1] < n:
             nbytes = self.lib.wsi_trunk_workspace_bytes(n, h, w, self.planes)
             if nbytes == 0:
                 raise ValueError('unsupported patch shape %dx%d (need multiples of 32) or batch %d' % (h, w, n))
+            self._ws.pop(key, None)                         # a smaller plan of the same shape is released first
+            if len(self._ws) >= 4 * max(1, len(self._streams)):   # keep the plan cache small
+                self._ws.pop(next(iter(self._ws)))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             native.check(self.lib.wsi_trunk_workspace_init(_ptr(ws), n, h, w, self.planes, _stream()),
                          'wsi_trunk_workspace_init')
-            if len(self._ws) >= 4 * max(1, len(self._streams)):   # keep the plan cache small
-                self._ws.pop(next(iter(self._ws)))
-            self._ws[key] = ws
-        return ws
+            ent = self._ws[key] = (ws, n)
+        return ent
 
     # ------------------------------------------------------------------ forward passes
     def _run(self, n, h, w, in_f32, slide, tile_xy, want_feat, want_logits, want_fmap, tap=None, slot=0):
-        ws = self._workspace(n, h, w, slot)
+        ws, cap = self._workspace(n, h, w, slot)
         dev = self.device
         feat = torch.empty((n, 512), dtype=torch.float32, device=dev) if want_feat else None
         logits = torch.empty((n, self.head_k), dtype=torch.float32, device=dev) if want_logits else None
@@ -173,11 +177,11 @@ class TrunkEngine:
             ww = w >> (2 + max(stage - 1, 0))
             out = torch.empty((n, c, hh, ww), dtype=torch.float32, device=dev)
             native.check(self.lib.wsi_trunk_forward_tap(C.byref(self.wt), _ptr(in_f32), sp, pitch, sh, sw, _ptr(tile_xy),
-                                                        _ptr(self.lut), n, h, w, _ptr(ws), tap, _ptr(out), _stream()),
+                                                        _ptr(self.lut), n, h, w, _ptr(ws), cap, tap, _ptr(out), _stream()),
                          'wsi_trunk_forward_tap')
             return out
         native.check(self.lib.wsi_trunk_forward(C.byref(self.wt), _ptr(in_f32), sp, pitch, sh, sw, _ptr(tile_xy),
-                                                _ptr(self.lut), n, h, w, _ptr(ws), _ptr(feat), _ptr(logits), _ptr(fmap),
+                                                _ptr(self.lut), n, h, w, _ptr(ws), cap, _ptr(feat), _ptr(logits), _ptr(fmap),
                                                 _stream()), 'wsi_trunk_forward')
         return feat, logits, fmap
 
@@ -214,6 +218,7 @@ class TrunkEngine:
     def _batched(self, n, run, h=256, w=256):
         """Split n images into max_batch chunks; with several chunks, alternate them over the side streams."""
         mb = self.max_batch if self.max_batch else max(1, int(2000 * 65536 // max(h * w, 1)))
+        mb = -(-n // max(1, -(-n // mb)))                  # equal-sized batches (no short tail): ceil(n / ceil(n / mb))
         starts = list(range(0, n, mb))
         if len(starts) == 1 or not self._streams:
             outs = [run(i, min(mb, n - i), 0) for i in starts]

@@ -57,8 +57,8 @@ SIGNATURES = {
     'wsi_pf_unpack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'wsi_trunk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'wsi_trunk_workspace_init': (_i, [_vp, _i, _i, _i, _i, _vp]),
-    'wsi_trunk_forward': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    'wsi_trunk_forward_tap': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'wsi_trunk_forward': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    'wsi_trunk_forward_tap': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'wsi_trunk_set_chunks': (_i, [_i, _i]),
     'wsi_prof_begin': (_i, [_i]),
     'wsi_prof_end': (_i, [_vp, _vp, _vp, _i]),
@@ -94,7 +94,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lost a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.wsi_hip_abi_version() != 1:
+    if lib.wsi_hip_abi_version() != 2:
         raise RuntimeError('libwsi_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -140,6 +140,107 @@ def gather_tile_logits(local_logits, total, rank, world):
     return torch.cat(parts, 0)
 
 
+# ------------------------------------------------------------------------------ rank-resident slide regions
+class SyntheticRows:
+    """Position-deterministic i.i.d. uniform u8 RGB slide level: rows are generated on the
+    device in blocks of `block` rows, block b from seed (seed, b), so ANY rank can produce ANY rectangle of the same
+    slide without holding the rest of it (40 000^2 x 3 = 4.8 GB when fully resident)."""
+
+    def __init__(self, iw, ih, seed, device, block=64):
+        self.iw, self.ih, self.seed, self.device, self.block = int(iw), int(ih), int(seed), torch.device(device), int(block)
+
+    def _block(self, b):
+        g = torch.Generator(device=self.device).manual_seed(self.seed * 1000003 + b)
+        rows = min(self.block, self.ih - b * self.block)
+        return torch.randint(0, 256, (rows, self.iw, 3), dtype=torch.uint8, device=self.device, generator=g)
+
+    def rect(self, x0, y0, x1, y1):
+        """(y1-y0, x1-x0, 3) uint8 tensor of slide[y0:y1, x0:x1] (bounds inside the slide)."""
+        out = torch.empty((y1 - y0, x1 - x0, 3), dtype=torch.uint8, device=self.device)
+        for b in range(y0 // self.block, (y1 - 1) // self.block + 1):
+            blk = self._block(b)
+            a, e = max(y0, b * self.block), min(y1, b * self.block + blk.shape[0])
+            out[a - y0:e - y0] = blk[a - b * self.block:e - b * self.block, x0:x1]
+        return out
+
+    def full(self):
+        return self.rect(0, 0, self.iw, self.ih)
+
+
+def region_plan(tile_xy, pw, ph):
+    """Cover a tile list by few rectangles and pack them into one atlas, so a rank keeps only the parts of the slide
+    its own tiles touch ("each GPU holds only its band").  Tile rows (same y) at least half as wide as
+    the widest one are merged vertically when they touch or overlap and have similar x-extents: a rank's interior
+    rows become one full-width band.  Narrow rows (a partial first / last row, the rank's share of the right-edge
+    column) stay single-row rectangles and are shelf-packed side by side under the bands.  Returns (rects, (atlas_h,
+    atlas_w), local_xy): rects = [(x0, y0, x1, y1, atlas_x, atlas_y)] in slide pixels, local_xy (T,2) int32 = each
+    tile's corner inside the atlas."""
+    xy = np.asarray(tile_xy, np.int64).reshape(-1, 2)
+    if len(xy) == 0:
+        return [], (1, max(1, pw)), np.zeros((0, 2), np.int32)
+    ys = np.unique(xy[:, 1])
+    ext = {}
+    for y in ys:
+        sel = xy[:, 1] == y
+        ext[int(y)] = (int(xy[sel, 0].min()), int(xy[sel, 0].max()) + pw)
+    wmax = max(x1 - x0 for x0, x1 in ext.values())
+    bands, narrow, row_rect = [], [], {}               # bands: [x0, y0, x1, y1]; row_rect: y -> ('b' | 'n', index)
+    for y in (int(v) for v in ys):
+        x0, x1 = ext[y]
+        if (x1 - x0) * 2 < wmax:
+            narrow.append([x0, y, x1, y + ph])
+            row_rect[y] = ('n', len(narrow) - 1)
+            continue
+        hit = None
+        for i, r in enumerate(bands):
+            inter = min(x1, r[2]) - max(x0, r[0])
+            union = max(x1, r[2]) - min(x0, r[0])
+            if y <= r[3] and inter * 2 >= union:       # touches / overlaps the band above it, similar extent
+                hit = i
+                break
+        if hit is None:
+            bands.append([x0, y, x1, y + ph])
+            hit = len(bands) - 1
+        else:
+            r = bands[hit]
+            r[0], r[2], r[3] = min(r[0], x0), max(r[2], x1), max(r[3], y + ph)
+        row_rect[y] = ('b', hit)
+    aw = max(r[2] - r[0] for r in bands + narrow)
+    ay, placed_b, placed_n = 0, [], []
+    for r in bands:
+        placed_b.append((r[0], r[1], r[2], r[3], 0, ay))
+        ay += r[3] - r[1]
+    ax = 0
+    for r in narrow:                                   # shelves of height ph
+        w = r[2] - r[0]
+        if ax + w > aw:
+            ax, ay = 0, ay + ph
+        placed_n.append((r[0], r[1], r[2], r[3], ax, ay))
+        ax += w
+    if narrow:
+        ay += ph
+    local = np.empty((len(xy), 2), np.int32)
+    for i, (x, y) in enumerate(xy):
+        kind, j = row_rect[int(y)]
+        r = (placed_b if kind == 'b' else placed_n)[j]
+        local[i] = (x - r[0] + r[4], y - r[1] + r[5])
+    return placed_b + placed_n, (ay, aw), local
+
+
+def resident_regions(source, rects, atlas_hw, device):
+    """Materialise the atlas of `region_plan`: a zero-filled (H, W, 3) uint8 device tensor holding every rectangle
+    (clipped to the slide; what hangs outside stays 0, like OpenSlide's transparent black).  `source` has
+    .iw, .ih and .rect(x0, y0, x1, y1) -> uint8 (h, w, 3) tensor or array."""
+    atlas = torch.zeros((atlas_hw[0], atlas_hw[1], 3), dtype=torch.uint8, device=device)
+    for x0, y0, x1, y1, ax, ay in rects:
+        cx0, cy0, cx1, cy1 = max(x0, 0), max(y0, 0), min(x1, source.iw), min(y1, source.ih)
+        if cx1 > cx0 and cy1 > cy0:
+            blk = source.rect(cx0, cy0, cx1, cy1)
+            blk = blk if isinstance(blk, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(blk))
+            atlas[ay + cy0 - y0:ay + cy1 - y0, ax + cx0 - x0:ax + cx1 - x0] = blk.to(device)
+    return atlas
+
+
 # ------------------------------------------------------------------------------ per-slide pipeline
 def _upload(arr, dtype, dev):
     """Host array -> device without blocking the host on the GPU queue: a pageable-memory copy waits for everything already
@@ -151,14 +252,18 @@ def _upload(arr, dtype, dev):
 
 
 def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classes, class_probs, mask_dev=None,
-                    rank=0, world=1, want_probs=True):
+                    rank=0, world=1, want_probs=True, local_xy=None):
     """predict_tumorbed(mode='cls') for one slide on device (reference utils/eval.py:182-229):
     this rank's tiles -> fused read+transform+trunk+classifier -> (RCCL gather) -> float64 stitch ->
-    softmax/threshold/argmax -> u8 heat map.  Returns dict of device tensors."""
+    softmax/threshold/argmax -> u8 heat map.  Returns dict of device tensors.
+    `slide_level_dev` is the whole level, or - with `local_xy` - this rank's atlas of resident regions
+    (region_plan / resident_regions) and local_xy the corners of ITS tiles [lo, hi) inside that atlas."""
     T = int(tile_xy.shape[0])
     lo, hi = shard_range(T, rank, world)
     dev = slide_level_dev.device
-    xy_dev = _upload(tile_xy[lo:hi], torch.int32, dev)
+    if local_xy is not None and len(local_xy) != hi - lo:
+        raise ValueError('local_xy must list this rank\'s %d tiles' % (hi - lo))
+    xy_dev = _upload(tile_xy[lo:hi] if local_xy is None else local_xy, torch.int32, dev)
     if hi > lo:
         _, logits, _ = eng.forward_tiles(slide_level_dev, xy_dev, ph, pw, logits=True)
     else:
