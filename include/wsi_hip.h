@@ -185,6 +185,39 @@ int wsi_stitch_add_dense(const float* tile_pred, const int* map_xy, int t, int c
 int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream);
 
+/* ---- tumour-bed post-process of the stitched map (all device memory; byte / integer / float64 work) ----------
+ * Bit-exact against oracle/postprocess_oracle.py, which restates the published algorithms of the third-party calls
+ * the reference makes here (OpenCV, scikit-image, mahotas: absent and un-pinned, so parity is unpinned by the
+ * reference itself).
+ *   wsi_resize_bilinear_f64  utils/eval.py:66-71   cv2.resize(pred[c], level_dimensions[2]) (INTER_LINEAR, float64)
+ *   wsi_argmax_classes       utils/eval.py:82      np.argmax(pred, 0) -> u8
+ *   wsi_morph_rect           utils/eval.py:91,95   cv2.erode (op 0) / cv2.dilate (op 1) / MORPH_OPEN (op 2), k x k ones,
+ *                                                  default anchor and border; tmp: h*w bytes, no aliasing
+ *   wsi_convex_hull_image    utils/eval.py:92      skimage convex_hull_image (offset_coordinates=True), exact predicate
+ *   wsi_bwperim              utils/eval.py:94      mahotas.bwperim(n=4)
+ *   wsi_tumor_bed            utils/eval.py:90-96 and paper_tools/overlay_tb_wsi.py:46-64 in one call:
+ *       (codes >= min_code) -> open k x k -> hull image (tb_pred_out) -> perimeter -> dilate (outline_out);
+ *       codes = class map with min_code 2, or u8 heat map with min_code ceil(0.9 * 255) = 230; opened_out may be NULL
+ *   wsi_hull_polygon         the hull of the last wsi_tumor_bed / wsi_convex_hull_image on this workspace as a closed
+ *                            (x, y) float64 contour (the ordered input of wsi_esp); count_out: device int
+ *   wsi_mask_iou_counts      utils/eval.py:104     out2 = {sum(a & b), sum(a | b)} (a, b compared != 0)
+ *   wsi_score_counts         utils/eval.py:107-121 out6 = {#(gt>0), #(p==gt & gt>0), sum|p-gt|, the reference's weight sum,
+ *                                                  #(p>0 & gt>0), #(p>0 | gt>0)}; p is multiplied by mask when given
+ *   wsi_esp                  contour_ordering.py:33-60  evenly_spaced_points_on_a_contour; scratch: n doubles */
+int wsi_resize_bilinear_f64(const double* src, int c, int hs, int ws, double* dst, int hd, int wd, void* stream);
+int wsi_argmax_classes(const double* pred, int c, long long hw, uint8_t* classes, void* stream);
+int wsi_morph_rect(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int h, int w, int k, int op, void* stream);
+int wsi_bwperim(const uint8_t* src, uint8_t* dst, int h, int w, void* stream);
+size_t wsi_tumor_bed_workspace_bytes(int h, int w);
+int wsi_convex_hull_image(const uint8_t* src, uint8_t* dst, int h, int w, void* workspace, void* stream);
+int wsi_tumor_bed(const uint8_t* codes, int h, int w, int min_code, int open_k, int dilate_k, uint8_t* opened_out,
+                  uint8_t* tb_pred_out, uint8_t* outline_out, void* workspace, void* stream);
+int wsi_hull_polygon(void* workspace, int h, int w, double* out_xy, int cap, int* count_out, void* stream);
+int wsi_mask_iou_counts(const uint8_t* a, const uint8_t* b, long long n, unsigned long long* out2, void* stream);
+int wsi_score_counts(const uint8_t* p, const uint8_t* gt, const uint8_t* mask, long long n, unsigned long long* out6,
+                     void* stream);
+int wsi_esp(const double* pts_xy, int n, int num_pts, double* out_xy, double* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

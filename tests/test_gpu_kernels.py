@@ -307,3 +307,39 @@ def test_random_shapes_sweep(dev, monkeypatch):
     path = os.path.join(os.path.dirname(__file__), 'studies', 'random_conv_shapes.py')
     monkeypatch.setattr(sys, 'argv', [path, '3', '12'])
     runpy.run_path(path, run_name='__main__')
+
+
+@pytest.mark.parametrize('shape', [(37, 128, 32, 32), (5, 128, 32, 32), (70, 256, 16, 16), (3, 256, 16, 16), (130, 512, 8, 8),
+                                   (9, 512, 8, 8), (2, 256, 2, 2), (3, 128, 64, 64), (1, 512, 1, 1)])
+def test_pingpong_conv_equals_wide_kernel(dev, shape):
+    """conv3x3s1_pp_kernel (cfg 70-72: 8-wave ping-pong schedule, double-buffered slab) is bit-identical to the slab3 kernel
+    (cfg 30) in every precision mode, with and without residual, ragged last tiles and tiny maps included; pad
+    positions stay untouched."""
+    import ctypes as C
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    lib = native.load()
+    n, c, h, w = shape
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(n * 7 + c)
+    x = torch.randn(n, c, h, w, generator=g).abs_()
+    r = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+    ran = 0
+    for planes in (3, 2, 1):
+        wpk, bias = E.prepack_conv(wt, None, planes, dev)
+        xpf, rpf = E.pf_pack(x.to(dev), planes), E.pf_pack(r.to(dev), planes)
+        for resid in (None, rpf):
+            for relu in (0, 1):
+                ref = E.pf_zeros(n, c, h, w, planes, dev)
+                native.check(lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), ref.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                                        wpk.data_ptr(), bias.data_ptr(), n, h, w, c, c, 1, relu, planes, 30, st), 'cfg 30')
+                for cfg in (70, 71, 72, 73, 74, 77, 78):
+                    out = E.pf_zeros(n, c, h, w, planes, dev)
+                    rc = lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), out.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                                    wpk.data_ptr(), bias.data_ptr(), n, h, w, c, c, 1, relu, planes, cfg, st)
+                    if rc == -22:
+                        continue                                  # shape outside this tile configuration (LDS budget, cout multiple)
+                    assert rc == 0
+                    assert torch.equal(out, ref), (shape, planes, cfg, resid is not None, relu)
+                    ran += 1
+    assert ran > 0 or c < 128 or w > 33                        # (maps wider than 33: two slabs of this tile do not fit)

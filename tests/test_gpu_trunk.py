@@ -225,7 +225,9 @@ def test_forward_is_bit_deterministic(dev, sd):
 @pytest.mark.parametrize('planes', [1, 2, 3])
 def test_trunk_set_chunks_equals_unchunked(dev, sd, planes):
     """wsi_trunk_set_chunks (sub-batches of the stem / layer-1 stages) must not change a single bit in any precision
-    mode (r01 bug: the per-image offset used 6 B/channel for the mx format, which has 4)."""
+    mode (r01 bug: the per-image offset used 6 B/channel for the mx format, which has 4).  A layer-1 chunk smaller
+    than the batch also gives up the phase-split hand-over to the wide stride-2 kernel (another kernel, another fp32
+    summation order), so those settings are compared with the unchunked run of THAT route (wsi_conv_set_mode + 128)."""
     from wsi_segmentation_pipeline_amd import native
     from wsi_segmentation_pipeline_amd.engine import TrunkEngine
     lib = native.load()
@@ -235,15 +237,23 @@ def test_trunk_set_chunks_equals_unchunked(dev, sd, planes):
     sl, xyd = torch.from_numpy(strip).to(dev), torch.from_numpy(xy).to(dev)
     eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']))
     x = R.normalize_u8(u8).to(dev)
-    base_t = [t.clone() for t in eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=True, fmap=True)]
-    base_f = [t.clone() for t in eng.forward_f32(x, feat=True, logits=True, fmap=True)]
+
+    def run():
+        return ([t.clone() for t in eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=True, fmap=True)] +
+                [t.clone() for t in eng.forward_f32(x, feat=True, logits=True, fmap=True)])
+    base = run()
     try:
-        for cs, c1 in ((2, 4), (1, 1), (3, 0), (0, 2)):
+        native.check(lib.wsi_conv_set_mode(1 + 128), 'wsi_conv_set_mode')
+        base_nosplit = run()
+        for a, b in zip(base, base_nosplit):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+        for cs, c1 in ((2, 4), (1, 1), (3, 0), (0, 2), (7, 7), (1, 7)):
+            native.check(lib.wsi_conv_set_mode(1), 'wsi_conv_set_mode')
             native.check(lib.wsi_trunk_set_chunks(cs, c1), 'wsi_trunk_set_chunks')
-            got_t = eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=True, fmap=True)
-            got_f = eng.forward_f32(x, feat=True, logits=True, fmap=True)
-            for a, b in zip(list(got_t) + list(got_f), base_t + base_f):
+            want = base if (c1 == 0 or c1 >= 7) else base_nosplit
+            for a, b in zip(run(), want):
                 assert torch.equal(a, b), (planes, cs, c1)
     finally:
         lib.wsi_trunk_set_chunks(0, 0)
+        lib.wsi_conv_set_mode(1)
     assert lib.wsi_trunk_set_chunks(2, 3) != 0                    # layer1 chunk must be a multiple of the stem chunk

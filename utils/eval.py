@@ -120,16 +120,32 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
     return results
 
 
+def _map_u8(arr, hw, dev):
+    """Ground-truth image -> uint8 (H,W) device tensor at map resolution (nearest-neighbour when the size differs; the
+    reference resizes with PIL's version-dependent default filter, utils/eval.py:77-78)."""
+    a = np.asarray(arr)
+    if a.ndim == 3:
+        a = a[..., 0]
+    if tuple(a.shape) != tuple(hw):
+        ys = (np.arange(hw[0]) * a.shape[0] // hw[0]).clip(0, a.shape[0] - 1)
+        xs = (np.arange(hw[1]) * a.shape[1] // hw[1]).clip(0, a.shape[1] - 1)
+        a = a[ys][:, xs]
+    return torch.from_numpy(np.ascontiguousarray(a.astype(np.uint8))).to(dev)
+
+
 def predict_wsis(model, dataset, ep, save=True):
-    """Dense per-pixel map prediction (reference utils/eval.py:22-152): `model(batch_image)` must return
-    (B, C, ph, pw) logits on the GPU (the reference drives a third-party smp model here; any GPU module
-    works).  The accumulate `pred[:, y:y+ph, x:x+pw] += pred_src[b]` (:58-60) runs on the device in
-    float64 at scan-level resolution (wsi_stitch_add_dense) - 51 GB for a 40k x 40k slide, which the
-    host-side reference cannot hold but HBM can - followed by the class arg-max (wsi_softmax_threshold_argmax).
-    Returns {key: {'pred': float64 (C,H,W) tensor, 'classes': u8 (H,W) tensor}} and writes
-    <val_save_pth>/<ep>/<key>_<stride>.png (class colours on the foreground mask).  The reference's
-    score printing and tumour-bed outline (cv2 / skimage / mahotas post-processing)
-    are not reproduced."""
+    """Dense per-pixel map prediction with the tumour-bed post-process (reference utils/eval.py:22-152).
+    `model(batch_image)` must return (B, C, ph, pw) logits on the GPU (the reference drives an smp U-Net here; any GPU
+    module works, e.g. wsi_segmentation_pipeline_amd.unet.UNetSeg).  Everything between the tile list and the colour
+    mask stays on the device:
+      :58-60    pred[:, y:y+ph, x:x+pw] += pred_src[b]      float64, scan-level resolution (wsi_stitch_add_dense)
+      :66-71    cv2.resize of every class map to level-2     wsi_resize_bilinear_f64
+      :82-96    argmax -> (p >= 2) -> open 20x20 -> convex hull -> perimeter -> dilate 20x20     wsi_tumor_bed
+      :100-123  tumour-bed IoU, accuracy / score figures against `entry['gt']` / `entry['tb_gt']` (when the dataset
+                entry carries them: the reference reads <wsipath>_mask.png / _tumor_bed.png)    wsi_score_counts, wsi_mask_iou_counts
+      :138-145  colour mask (threshold_probs classes on the foreground mask, tumour-bed outline in white), saved at half size
+    Returns {key: {'pred', 'pred_level2', 'classes' (scan level), 'classes_level2', 'tumor_bed', 'outline', 'scores'}}."""
+    from wsi_segmentation_pipeline_amd import postprocess as PP
     out_dir = '{}/{}'.format(args.val_save_pth, ep)
     if save:
         os.makedirs(out_dir, exist_ok=True)
@@ -137,6 +153,7 @@ def predict_wsis(model, dataset, ep, save=True):
     was_training = model.training
     model.eval()
     results = {}
+    ious_tb = 0.0
     with torch.no_grad():
         for key in list(dataset.wsis):
             entry = dataset.wsis[key]
@@ -150,24 +167,55 @@ def predict_wsis(model, dataset, ep, save=True):
                     raise ValueError('predict_wsis needs a dense model returning (B, %d, ph, pw)' % args.num_classes)
                 xy = torch.stack((batch_x, batch_y), 1).to(torch.int32)        # int(batch_x[bj]): truncation
                 E.stitch_add_dense(pred, pred_src, xy)
-            classes, _, _ = E.softmax_threshold_argmax(pred, [0.0] * args.num_classes, want_probs=False)
-            results[key] = {'pred': pred, 'classes': classes}
-            if save:
-                cls = classes.cpu().numpy()
-                mask = entry.get('mask')
-                rgb = np.zeros(cls.shape + (3,), np.uint8)
-                for cj in range(min(args.num_classes - 1, 3)):                  # class k>0 -> channel k-1, like pred_to_mask
-                    rgb[cls == cj + 1, cj] = 255
-                if mask is not None and tuple(mask.shape) != cls.shape:
-                    ys = (np.arange(cls.shape[0]) * mask.shape[0] // cls.shape[0]).clip(0, mask.shape[0] - 1)
-                    xs = (np.arange(cls.shape[1]) * mask.shape[1] // cls.shape[1]).clip(0, mask.shape[1] - 1)
-                    mask = np.asarray(mask)[ys][:, xs]
-                if mask is not None:
-                    rgb = rgb * (np.asarray(mask) > 0)[..., None].astype(np.uint8)
-                _save_png(rgb, '{}/{}_{}.png'.format(out_dir, key, args.tile_stride_w))
+            classes = PP.argmax_classes(pred)
+            ref_level = min(2, len(scan.level_dimensions) - 1)
+            map_hw = tuple(scan.level_dimensions[ref_level][::-1])
+            pred2 = PP.resize_bilinear(pred, map_hw)                           # :66-71
+            p = PP.argmax_classes(pred2)                                       # :82
+            tb = PP.tumor_bed(p, 2, 20, 20)                                    # :90-96
+            mask = entry.get('mask')
+            mask_dev = _map_u8(mask, map_hw, dev) if mask is not None else torch.ones(map_hw, dtype=torch.uint8, device=dev)
+            scores = None
+            if entry.get('gt') is not None:                                    # :74-135
+                scores = PP.wsi_scores(p, _map_u8(entry['gt'], map_hw, dev), (mask_dev > 0).to(torch.uint8), args.epsilon)
+                scores['iou_tb'] = -1
+                if entry.get('tb_gt') is not None:
+                    scores['iou_tb'] = PP.mask_iou((_map_u8(entry['tb_gt'], map_hw, dev) > 0).to(torch.uint8), tb.tb_pred, args.epsilon)
+                    ious_tb += scores['iou_tb']
+                print('{}, {:.3f}({:.3f}), {:.3f}({:.3f}), {:.3f}, tb iou: {:.3f} '.format(
+                    key, scores['s_masked'], scores['s'], scores['acc_masked'], scores['acc'], scores['iou_fg'], scores['iou_tb']))
+            results[key] = {'pred': pred, 'pred_level2': pred2, 'classes': classes, 'classes_level2': p,
+                            'tumor_bed': tb.tb_pred, 'outline': tb.outline, 'scores': scores}
+            if save:                                                           # :138-145
+                cls_thr = E.softmax_threshold_argmax(pred2, args.class_probs, want_probs=False)[0]      # pred_to_mask
+                rgb = torch.zeros(map_hw + (3,), dtype=torch.uint8, device=dev)
+                for cj in range(min(args.num_classes - 1, 3)):                  # class k > 0 -> channel k - 1
+                    rgb[..., cj] = (cls_thr == cj + 1).to(torch.uint8) * 255
+                rgb = rgb * mask_dev[..., None]
+                rgb[tb.outline > 0] = 255
+                from PIL import Image
+                img = Image.fromarray(rgb.cpu().numpy())
+                img.resize((max(1, map_hw[1] // 2), max(1, map_hw[0] // 2))).save('{}/{}_{}.png'.format(out_dir, key, args.tile_stride_w))
+        if dataset.wsis:
+            print('Average tb iou: {:.3f}'.format(ious_tb / len(dataset.wsis)))
     if was_training:
         model.train()
     return results
+
+
+def tumor_bed_overlay(heat_u8, thumb_rgb=None):
+    """The tumour-bed outline of a stitched u8 heat map (reference paper_tools/overlay_tb_wsi.py:46-64) on the device:
+    (heat / 255 >= 0.9) -> open 30x30 -> convex hull -> perimeter -> dilate 20x20.  Returns the
+    wsi_segmentation_pipeline_amd.postprocess.TumorBed (opened mask, hull image, outline, .outline_points(n) via esp) and,
+    with a (H,W,3) u8 thumbnail on the GPU, the overlay 0.65 * wsi + 0.35 * (heat * opened) with the outline in black."""
+    from wsi_segmentation_pipeline_amd import postprocess as PP
+    tb = PP.tumor_bed_from_heatmap(heat_u8, 0.9, 30, 20)
+    if thumb_rgb is None:
+        return tb, None
+    hm = (heat_u8 * tb.opened).to(torch.float64)[..., None].expand(-1, -1, 3)
+    over = 0.65 * thumb_rgb.to(torch.float64) + 0.35 * hm
+    over[tb.outline > 0] = 0
+    return tb, over.to(torch.uint8)
 
 
 def predict_regions(model, iterator, metadata, label_shape, class_probs=None):

@@ -25,6 +25,18 @@ int wsi_stitch_add_dense_dispatch(const float* tiles, const int* txy, int T, int
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
                          const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
 
+int wsi_resize_dispatch(const double* src, int C, int Hs, int Ws, double* dst, int Hd, int Wd, hipStream_t st);
+int wsi_argmax_dispatch(const double* pred, int C, long long HW, uint8_t* classes, hipStream_t st);
+int wsi_threshold_dispatch(const uint8_t* src, long long n, int lo, uint8_t* dst, hipStream_t st);
+int wsi_morph_dispatch(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int H, int W, int k, int op, hipStream_t st);
+int wsi_bwperim_dispatch(const uint8_t* src, uint8_t* dst, int H, int W, hipStream_t st);
+size_t wsi_hull_ws_bytes(int H);
+int wsi_hull_dispatch(const uint8_t* src, uint8_t* dst, int H, int W, void* ws, hipStream_t st);
+int wsi_hull_polygon_dispatch(void* ws, int H, double* out_xy, int cap, hipStream_t st);
+int wsi_iou_counts_dispatch(const uint8_t* a, const uint8_t* b, long long n, unsigned long long* out, hipStream_t st);
+int wsi_score_counts_dispatch(const uint8_t* p, const uint8_t* gt, const uint8_t* mask, long long n, unsigned long long* out, hipStream_t st);
+int wsi_esp_dispatch(const double* pts, int n, int num, double* out, double* scratch, hipStream_t st);
+
 // ------------------------------------------------------------------------------------ host helpers
 static inline uint16_t f2bf(float f) {            // round-to-nearest-even, same as the device cast
     uint32_t u;
@@ -294,6 +306,11 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
 static int g_s2_slab = 1;                             // stride-2 convs: phase-slab kernel (1) or per-tap gather kernel (0)
 static int g_s2_split = 1;                            // trunk: phase-split stage outputs + wide stride-2 kernel (A/B: wsi_conv_set_mode +128 off)
 
+#ifdef WSI_STUDY
+static void* g_study_debug = nullptr;                 // study builds: device buffer handed to stamped kernels through ConvArgs.out2
+extern "C" int wsi_study_set_debug(void* dev_buf) { g_study_debug = dev_buf; return WSI_OK; }
+#endif
+
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
                        int cfg = -1, int split_out = 0, long long split_pixels = 0) {
@@ -303,8 +320,25 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.in = in_pf; a.out = out_pf; a.resid = resid_pf; a.wpk = wpk; a.bias = bias;
     a.gi = pf_geom(n, h_in, w_in, cin);
     a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
-    a.stride = stride; a.ksize = ksize; a.relu = relu;
+    a.stride = stride; a.ksize = ksize; a.relu = relu & 1; a.flags = 0;
+#ifdef WSI_STUDY
+    // study builds accept the r01 ablation masks of tools/tune_conv.py in `relu` (2 no stores, 64 dispatch only, 128 no main
+    // loop, 256 non-temporal, bits 10-13 weight copies, 512 / 16384 XCD orders, 65536 residual read directly)
+    if (relu & 2) a.flags |= CONV_ABL_NO_STORE;
+    if (relu & 64) a.flags |= CONV_ABL_DISPATCH_ONLY;
+    if (relu & 128) a.flags |= CONV_ABL_NO_MAINLOOP;
+    if (relu & 256) a.flags |= CONV_NONTEMPORAL;
+    if (relu & 512) a.flags |= CONV_XCD_ORDER;
+    if (relu & 16384) a.flags |= CONV_XCD_RANGES;
+    if (relu & 65536) a.flags |= CONV_RESID_DIRECT;
+    a.flags |= ((relu >> 10) & 15) << CONV_WCOPIES_SHIFT;
+#else
+    if (relu & ~1) return WSI_EINVAL;
+#endif
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
+#ifdef WSI_STUDY
+    if (cfg == 75 || cfg == 76) a.out2 = g_study_debug;
+#endif
     a.in_split_pixels = 0;
     // distance between the four phase images: the caller's (a workspace planned for more images) or the tight one
     a.out_split_pixels = split_out ? (split_pixels ? split_pixels : pf_alloc_pixels(n, h_in / 2, w_in / 2)) : 0;
@@ -352,7 +386,7 @@ static int s2_split_common(const void* in_split, void* out_conv_pf, void* out_ds
     a.in = in_split; a.out = out_conv_pf; a.resid = nullptr; a.wpk = wpk3; a.bias = bias3;
     a.gi = pf_geom(n, h_in, w_in, cin);
     a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
-    a.stride = 2; a.ksize = 3; a.relu = 1;
+    a.stride = 2; a.ksize = 3; a.relu = 1; a.flags = 0;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
     a.out_split_pixels = 0;
     a.in_split_pixels = split_pixels ? split_pixels : pf_alloc_pixels(n, h_in / 2, w_in / 2);
@@ -375,7 +409,7 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     a.in = in_pf; a.out = out_conv_pf; a.resid = nullptr; a.wpk = wpk3; a.bias = bias3;
     a.gi = pf_geom(n, h_in, w_in, cin);
     a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
-    a.stride = 2; a.ksize = 3; a.relu = 1;
+    a.stride = 2; a.ksize = 3; a.relu = 1; a.flags = 0;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
     a.in_split_pixels = 0; a.out_split_pixels = 0;
     int rc = wsi_s2_dispatch(a, planes, (hipStream_t)stream);
@@ -449,6 +483,69 @@ int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const 
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream) {
     if (!pred || !class_thresh) return WSI_EINVAL;
     return wsi_softmax_dispatch(pred, c, hw, class_thresh, probs, classes, mask, heat_mode, heat, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ tumour-bed post-process
+int wsi_resize_bilinear_f64(const double* src, int c, int hs, int ws, double* dst, int hd, int wd, void* stream) {
+    if (!src || !dst || src == dst) return WSI_EINVAL;
+    return wsi_resize_dispatch(src, c, hs, ws, dst, hd, wd, (hipStream_t)stream);
+}
+int wsi_argmax_classes(const double* pred, int c, long long hw, uint8_t* classes, void* stream) {
+    if (!pred || !classes) return WSI_EINVAL;
+    return wsi_argmax_dispatch(pred, c, hw, classes, (hipStream_t)stream);
+}
+int wsi_morph_rect(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int h, int w, int k, int op, void* stream) {
+    if (!src || !dst || !tmp) return WSI_EINVAL;
+    return wsi_morph_dispatch(src, dst, tmp, h, w, k, op, (hipStream_t)stream);
+}
+int wsi_bwperim(const uint8_t* src, uint8_t* dst, int h, int w, void* stream) {
+    if (!src || !dst) return WSI_EINVAL;
+    return wsi_bwperim_dispatch(src, dst, h, w, (hipStream_t)stream);
+}
+size_t wsi_tumor_bed_workspace_bytes(int h, int w) {
+    if (h <= 0 || w <= 0) return 0;
+    return 3 * align_up((size_t)h * w, 256) + align_up(wsi_hull_ws_bytes(h), 256);
+}
+int wsi_convex_hull_image(const uint8_t* src, uint8_t* dst, int h, int w, void* workspace, void* stream) {
+    if (!src || !dst || !workspace || src == dst) return WSI_EINVAL;
+    return wsi_hull_dispatch(src, dst, h, w, (char*)workspace + 3 * align_up((size_t)h * w, 256), (hipStream_t)stream);
+}
+int wsi_tumor_bed(const uint8_t* codes, int h, int w, int min_code, int open_k, int dilate_k, uint8_t* opened_out,
+                  uint8_t* tb_pred_out, uint8_t* outline_out, void* workspace, void* stream) {
+    if (!codes || !tb_pred_out || !outline_out || !workspace || h <= 0 || w <= 0 || open_k <= 0 || dilate_k <= 0 ||
+        tb_pred_out == outline_out)
+        return WSI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = align_up((size_t)h * w, 256);
+    uint8_t *A = (uint8_t*)workspace, *B = A + plane, *Cc = B + plane;
+    void* hws = Cc + plane;
+    int rc = wsi_threshold_dispatch(codes, (long long)h * w, min_code, A, st);
+    if (!rc) rc = wsi_morph_dispatch(A, B, Cc, h, w, open_k, 2, st);                 // MORPH_OPEN
+    if (!rc && opened_out && hipMemcpyAsync(opened_out, B, (size_t)h * w, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = WSI_EFAULT;
+    if (!rc) rc = wsi_hull_dispatch(B, tb_pred_out, h, w, hws, st);                  // chull
+    if (!rc) rc = wsi_bwperim_dispatch(tb_pred_out, A, h, w, st);                    // bwperim
+    if (!rc) rc = wsi_morph_dispatch(A, outline_out, Cc, h, w, dilate_k, 1, st);     // dilate
+    return rc;
+}
+int wsi_hull_polygon(void* workspace, int h, int w, double* out_xy, int cap, int* count_out, void* stream) {
+    if (!workspace || !out_xy || !count_out || h <= 0 || w <= 0 || cap <= 0) return WSI_EINVAL;
+    char* hws = (char*)workspace + 3 * align_up((size_t)h * w, 256);
+    int rc = wsi_hull_polygon_dispatch(hws, h, out_xy, cap, (hipStream_t)stream);
+    if (rc) return rc;
+    const int* counts = (const int*)hws + 2 * (2 * (size_t)h + 1);
+    return hipMemcpyAsync(count_out, counts + 2, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+int wsi_mask_iou_counts(const uint8_t* a, const uint8_t* b, long long n, unsigned long long* out2, void* stream) {
+    if (!a || !b || !out2) return WSI_EINVAL;
+    return wsi_iou_counts_dispatch(a, b, n, out2, (hipStream_t)stream);
+}
+int wsi_score_counts(const uint8_t* p, const uint8_t* gt, const uint8_t* mask, long long n, unsigned long long* out6, void* stream) {
+    if (!p || !gt || !out6) return WSI_EINVAL;
+    return wsi_score_counts_dispatch(p, gt, mask, n, out6, (hipStream_t)stream);
+}
+int wsi_esp(const double* pts_xy, int n, int num_pts, double* out_xy, double* scratch, void* stream) {
+    if (!pts_xy || !out_xy || !scratch) return WSI_EINVAL;
+    return wsi_esp_dispatch(pts_xy, n, num_pts, out_xy, scratch, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ profiler

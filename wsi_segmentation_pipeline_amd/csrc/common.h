@@ -85,7 +85,8 @@ struct ConvArgs {
     PFGeom gi, go;         // input / output geometry
     int stride;            // 1 or 2
     int ksize;             // 3 or 1
-    int relu;
+    int relu;              // 0 / 1: ReLU after bias (+ residual)
+    int flags;             // CONV_* below
     // fused 1x1 stride-2 downsample branch of the stride-2 kernel (all null when unused)
     void* out2;            // PF activations shaped like out
     const void* wpk2;      // 1x1 weights [ntile][line][1][f][lane][8]
@@ -95,6 +96,21 @@ struct ConvArgs {
     // 0 = ordinary PF.  out_split_pixels: the epilogue writes `out` phase-split; in_split_pixels: `in` is phase-split.
     long long out_split_pixels, in_split_pixels;
 };
+
+// ConvArgs.flags.  Product flags first; the CONV_ABL_* / study ones only act in builds with -DWSI_STUDY (bottleneck
+// studies: tools/tune_conv.py), where some of them produce wrong or missing outputs by design.
+enum : int {
+    CONV_XCD_ORDER = 1,        // the channel blocks of one pixel tile get workgroup ids 8 apart (same XCD / L2)
+    CONV_XCD_RANGES = 2,       // every XCD walks a contiguous range of pixel tiles (neighbours share halo rows in its L2)
+    CONV_RESID_DIRECT = 4,     // A/B: residual read straight from memory instead of LDS-DMA staging
+    CONV_ABL_NO_STORE = 1 << 8, CONV_ABL_DISPATCH_ONLY = 1 << 9, CONV_ABL_NO_MAINLOOP = 1 << 10, CONV_NONTEMPORAL = 1 << 11,
+    CONV_WCOPIES_SHIFT = 16,   // bits 16-19: back-to-back copies of the packed weights minus one
+};
+#ifdef WSI_STUDY
+#define CONV_STUDY(a, bits) ((a).flags & (bits))
+#else
+#define CONV_STUDY(a, bits) 0
+#endif
 
 // byte offset of output position q (a real pixel of geometry g) in an ordinary or phase-split tensor
 static inline __device__ size_t pf_out_offset(const PFGeom& g, long long split_pixels, int q, size_t pixstride) {

@@ -12,290 +12,7 @@
 // fp32 accumulate): ~2^-16 relative operand error, needed for the 1e-3 logit contract
 // (single-pass bf16 is 1.9e-2 off).  PLANES=1 is the single-pass bf16
 // speed mode.
-#include "common.h"
-
-// --------------------------------------------------------------------------------------------
-// Fused epilogue: bias (+ residual) (+ ReLU), split to bf16 planes, store.  acc[mt] covers
-// pixels q_base + mt*32 + (lane&31) and channels ntile*32 + 8g + 4h + i.
-// --------------------------------------------------------------------------------------------
-// 16-byte LDS-DMA: lane i writes LDS [lds_wave_base + 16*i] from its own global address.
-static __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// Buffer-addressed form: source = resource base + 32-bit per-lane byte offset + scalar offset (no
-// 64-bit address VALU).  Kept in a plain __device__ function: used directly inside a kernel
-// template, this builtin makes hipcc's host pass drop the kernel stub (ROCm 7.2).
-static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-// Residual tile (32 pixels x one 128-byte line) -> 4 KB of LDS at dst by LDS-DMA, eight lanes per line: piece
-// i = j*64 + lane is slot (i & 7) of tile pixel i >> 3, stored swizzled like the pixel slabs (source-side XOR).  q = this
-// lane's own pixel (PF index; lanes p and p+32 hold the same); the owning lanes hand it out by ds_bpermute.
-static __device__ __forceinline__ void resid_tile_dma(const void* resid, int q_own, size_t pixstride, size_t line_off, int lane, char* dst) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pp = 8 * j + (lane >> 3);
-        const int q = __shfl(q_own, pp);
-        const int sl = (lane & 7) ^ ((pp >> 1) & 7);
-        dma16((const char*)resid + (size_t)q * pixstride + line_off + sl * 16, dst + j * 1024);
-    }
-}
-
-template <int MT, int PLANES>
-static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
-                                                       const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
-    const int h = lane >> 5, l31 = lane & 31;
-    const size_t pixstride = (size_t)a.go.C * PFmt<PLANES>::BPC;
-    const size_t chan_off = (size_t)ntile * (32 * PFmt<PLANES>::BPC) + (size_t)(4 * h) * 2;
-    size_t poff[MT], ooff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        poff[mt] = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + chan_off;   // invalid rows read a real pixel, store nothing
-        ooff[mt] = a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, valid[mt] ? qs[mt] : a.go.G, pixstride) + chan_off : poff[mt];
-    }
-
-    // residual: with `scratch` (8 KB of wave-private LDS, split precision) tile by tile through LDS-DMA, line-contiguous
-    // (see conv_epilogue_mx); otherwise every residual load of the tile in flight at once (branch-free)
-    const bool via_lds = PLANES == 2 && a.resid && scratch;
-    bf16x4 rh[MT][4], rl[MT][4];
-    if (via_lds) {
-        resid_tile_dma(a.resid, valid[0] ? qs[0] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch);
-    } else if (a.resid) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const char* rp = (const char*)a.resid + poff[mt] + 16 * g;
-                if (a.relu & 256) {
-                    rh[mt][g] = __builtin_nontemporal_load((const bf16x4*)rp);
-                    if constexpr (PLANES == 2) rl[mt][g] = __builtin_nontemporal_load((const bf16x4*)(rp + 64));
-                } else {
-                    rh[mt][g] = *(const bf16x4*)rp;
-                    if constexpr (PLANES == 2) rl[mt][g] = *(const bf16x4*)(rp + 64);
-                }
-            }
-    }
-    float bias[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
-    // phase 2: bias + residual + ReLU, split, store
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        if (via_lds) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // tile mt has landed (and the previous tile's stores)
-            if (mt + 1 < MT)
-                resid_tile_dma(a.resid, valid[mt + 1] ? qs[mt + 1] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch + ((mt + 1) & 1) * 4096);
-            const char* t = scratch + (mt & 1) * 4096 + l31 * 128 + 8 * h;
-            const int sw = (l31 >> 1) & 7;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                rh[mt][g] = *(const bf16x4*)(t + ((g ^ sw) << 4));
-                rl[mt][g] = *(const bf16x4*)(t + (((4 + g) ^ sw) << 4));
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = acc[mt][4 * g + i] + bias[4 * g + i];
-            if (a.resid) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += (float)rh[mt][g][i];
-                if constexpr (PLANES == 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)rl[mt][g][i];
-                }
-            }
-            if (a.relu & 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hi[i] = (__bf16)v[i];
-                lo[i] = (__bf16)(v[i] - (float)hi[i]);
-            }
-            if (valid[mt] && !(a.relu & 2)) {
-                char* op = (char*)a.out + ooff[mt] + 16 * g;
-                if (a.relu & 256) {
-                    __builtin_nontemporal_store(hi, (bf16x4*)op);
-                    if constexpr (PLANES == 2) __builtin_nontemporal_store(lo, (bf16x4*)(op + 64));
-                } else {
-                    *(bf16x4*)op = hi;
-                    if constexpr (PLANES == 2) *(bf16x4*)(op + 64) = lo;
-                }
-            }
-        }
-    }
-}
-
-// Mode-3 epilogue (fp16 hi + MX-fp4).  Lane (pixel, h) owns line positions 16h .. 16h+15 (common.h mx_line_pos):
-// 32 contiguous bytes of fp16 and 8 bytes of each fp4 plane.  Block maxima need one exchange with lane^32; the
-// fp4 planes are swapped between the two lanes so each writes one 16-byte piece (h=0: lo4 of all 32, h=1: hi4).
-// Four store instructions per 32x32 tile (2 x 16 B fp16, 16 B fp4, 4 B scale) and four loads for a residual.
-// Residual: `scratch` (8 KB of LDS private to the wave, or null) selects how the residual tile is read.  Read straight
-// from memory, a load instruction touches 32 different 128-byte lines (one per pixel) and the four loads of a tile cost
-// four TCP look-ups per line: measured 3.8 TB/s on the residual bytes and -18 % on a layer-1 launch when the same bytes
-// are fetched line-contiguously (r01 study).  With scratch the tile (32 lines = 4 KB) is fetched by LDS-DMA, eight lanes
-// per line (pixel indices come from the owning lanes by ds_bpermute; slot swizzle applied on the source side), the
-// next tile's DMA in flight while this one is converted, and each lane then reads its share from LDS.
-template <int MT>
-static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
-                                                        const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
-    const int h = lane >> 5, l31 = lane & 31;
-    const size_t pixstride = (size_t)a.go.C * 4;
-    float bias[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
-    const float lo_clamp = (a.relu & 1) ? 0.f : -65504.f;
-    const bool via_lds = a.resid && scratch;
-    auto rdma = [&](int mt) {                                 // residual tile mt -> scratch buffer mt & 1
-        resid_tile_dma(a.resid, valid[mt] ? qs[mt] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch + (mt & 1) * 4096);
-    };
-    if (via_lds) rdma(0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * 128;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[mt][r] + bias[r];
-        if (a.resid) {
-            f16x8 r0, r1;
-            uint2 nib;
-            unsigned rs;
-            if (via_lds) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // tile mt has landed (and the previous tile's stores)
-                if (mt + 1 < MT) rdma(mt + 1);
-                const char* t = scratch + (mt & 1) * 4096 + l31 * 128;
-                const int sw = (l31 >> 1) & 7;
-                r0 = *(const f16x8*)(t + (((2 * h) ^ sw) << 4));
-                r1 = *(const f16x8*)(t + (((2 * h + 1) ^ sw) << 4));
-                nib = *(const uint2*)(t + ((4 ^ sw) << 4) + 8 * h);
-                rs = *(const unsigned*)(t + ((6 ^ sw) << 4)) & 255u;
-            } else {
-                const char* rl = (const char*)a.resid + loff;
-                r0 = *(const f16x8*)(rl + 32 * h);
-                r1 = *(const f16x8*)(rl + 32 * h + 16);
-                nib = *(const uint2*)(rl + 64 + 8 * h);                              // lo4 of this lane's 16 positions
-                rs = *(const unsigned*)(rl + 96) & 255u;                             // residual's scale_lo
-            }
-            const float rscale = rs ? mx4_scale_value((int)rs) : 0.f;
-            float d[16];
-            mx4_unpack8(nib.x, rscale, d);
-            mx4_unpack8(nib.y, rscale, d + 8);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                v[r] += (float)r0[r] + d[r];
-                v[8 + r] += (float)r1[r] + d[8 + r];
-            }
-        }
-        float lo[16], mh = 0.f, ml = 0.f;
-        f16x8 hv[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = __builtin_amdgcn_fmed3f(v[r], lo_clamp, 65504.f);              // ReLU (if any) + fp16-range clamp in one op
-            const _Float16 hh = (_Float16)v[r];
-            hv[r >> 3][r & 7] = hh;
-            lo[r] = v[r] - (float)hh;
-            v[r] = (float)hh;                                                       // v now holds hi
-            mh = fmaxf(mh, fabsf(v[r]));
-            ml = fmaxf(ml, fabsf(lo[r]));
-        }
-        mh = fmaxf(mh, __shfl_xor(mh, 32));
-        ml = fmaxf(ml, __shfl_xor(ml, 32));
-        const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
-        const float fh = sh ? mx4_scale_value(sh) : 1.f, fl = sl ? mx4_scale_value(sl) : 1.f;
-        const unsigned ql[2] = {mx4_pack8(lo, fl), mx4_pack8(lo + 8, fl)}, qh[2] = {mx4_pack8(v, fh), mx4_pack8(v + 8, fh)};
-        // lane h=0 keeps lo4 and receives the partner's lo4; lane h=1 keeps hi4 and receives the partner's hi4
-        const unsigned s0 = __shfl_xor(h ? ql[0] : qh[0], 32), s1 = __shfl_xor(h ? ql[1] : qh[1], 32);
-        const u32x4 q4 = h ? u32x4{s0, s1, qh[0], qh[1]} : u32x4{ql[0], ql[1], s0, s1};
-        if (valid[mt] && !(a.relu & 2)) {
-            char* ol = (char*)a.out + (a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, qs[mt], pixstride) + (size_t)ntile * 128 : loff);
-            *(f16x8*)(ol + 32 * h) = hv[0];
-            *(f16x8*)(ol + 32 * h + 16) = hv[1];
-            *(u32x4*)(ol + 64 + 16 * h) = q4;
-            const unsigned sc = (unsigned)(h ? sh : sl);                          // replicated: the whole 128-byte line is written
-            *(u32x4*)(ol + 96 + 16 * h) = u32x4{sc, sc, sc, sc};              // (no partial-line writes), readers pick any dword
-        }
-    }
-}
-
-// contiguous-position form: tile rows are PF positions q_base + mt*32 + (lane&31), pads filtered here
-template <int MT, int PLANES>
-static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT], int q_base, int ntile,
-                                                     int lane) {
-    int qs[MT];
-    bool valid[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        qs[mt] = q_base + mt * 32 + (lane & 31);
-        valid[mt] = pf_is_pixel(a.go, qs[mt]);
-    }
-    conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
-}
-
-template <int MT, int PLANES>
-static __device__ __forceinline__ void conv_epilogue_any(const ConvArgs& a, f32x16 (&acc)[MT], int q_base, int ntile, int lane) {
-    if constexpr (PLANES == 3) {
-        int qs[MT];
-        bool valid[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            qs[mt] = q_base + mt * 32 + (lane & 31);
-            valid[mt] = pf_is_pixel(a.go, qs[mt]);
-        }
-        conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
-    } else {
-        conv_epilogue<MT, PLANES>(a, acc, q_base, ntile, lane);
-    }
-}
-
-// One 128-byte line of K for MT pixel tiles: 4 fragments per operand; the pixel fragments of tile
-// mt+1 are requested before the MFMAs of tile mt so the LDS latency hides behind them.
-template <int MT, int PLANES>
-static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8 (&wf)[4], const char* smem,
-                                                 const int (&xbase)[MT]) {
-    bf16x8 xf[2][4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) xf[0][f] = *(const bf16x8*)(smem + (xbase[0] ^ (f << 5)));
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8(&x)[4] = xf[mt & 1];
-        if (mt + 1 < MT) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f) xf[(mt + 1) & 1][f] = *(const bf16x8*)(smem + (xbase[mt + 1] ^ (f << 5)));
-        }
-        if constexpr (PLANES == 2) {
-            acc[mt] = mfma_bf16(wf[2], x[0], acc[mt]);   // lo*hi
-            acc[mt] = mfma_bf16(wf[3], x[1], acc[mt]);
-            acc[mt] = mfma_bf16(wf[0], x[2], acc[mt]);   // hi*lo
-            acc[mt] = mfma_bf16(wf[1], x[3], acc[mt]);
-            acc[mt] = mfma_bf16(wf[0], x[0], acc[mt]);   // hi*hi
-            acc[mt] = mfma_bf16(wf[1], x[1], acc[mt]);
-        } else {
-#pragma unroll
-            for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(wf[f], x[f], acc[mt]);
-        }
-    }
-}
-
-// LDS byte offset of slot-pair base for slab-local pixel Pl and lane half h (swizzled):
-// slot s = 2f + h is stored at slot s ^ ((Pl>>1)&7); fragment f is reached by XOR (f<<5).
-static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128 + ((h ^ ((Pl >> 1) & 7)) << 4); }
-// Mode 3: the block-scale dword of pixel Pl (slot 6 + h, replicated in all four dwords of the slot).  Reading dword
-// (Pl & 1) + 2 * ((Pl >> 4) & 1) spreads 32 consecutive pixels over all 32 banks of a ds_read_b32.
-static __device__ __forceinline__ bf16x8 lds_xscale(const char* smem, int base, int Pl) {
-    const unsigned sc = *(const unsigned*)(smem + (base ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1)));
-    return __builtin_bit_cast(bf16x8, u32x4{sc, 0u, 0u, 0u});
-}
+#include "conv_dev.h"
 
 // --------------------------------------------------------------------------------------------
 // Generic gather kernel (3x3 stride 2, 1x1 stride 2, also stride 1): per (line, tap) step the BM
@@ -392,7 +109,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     constexpr int BM = WM * MT * 32;
     constexpr int NTHREADS = WM * WN * 64;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (a.relu & 64) return;                                  // ablation: dispatch cost only
+    if (CONV_STUDY(a, CONV_ABL_DISPATCH_ONLY)) return;         // study builds: dispatch cost only
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
@@ -401,13 +118,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     // bit 512 the channel blocks of one pixel tile get ids 8 apart, i.e. the SAME XCD, so the slab they share is
     // fetched from HBM once instead of once per channel block.
     int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
-    if (a.relu & 512) {
+    if (a.flags & CONV_XCD_ORDER) {
         const int per = 8 * nblocks, r = blockIdx.x % per;
         nb = r >> 3;
         mtile = (blockIdx.x / per) * 8 + (r & 7);
         const int mtiles = DENSE ? (a.gi.N * a.gi.H * a.gi.W + BM - 1) / BM : (a.gi.NS + BM - 1) / BM;
         if (mtile >= mtiles) return;
-    } else if (a.relu & 16384) {
+    } else if (a.flags & CONV_XCD_RANGES) {
         // XCD-contiguous ranges: XCD x (= id & 7) walks tiles [x*chunk, (x+1)*chunk) in dispatch order, so the halo rows
         // two neighbouring pixel tiles share are still in THAT XCD's L2 when the second one asks for them
         const int chunk = gridDim.x >> 3, lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -418,7 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     }
     const int P = a.gi.P;
     const int ntile = nb * WN + wn;
-    const int NC = (a.relu & 128) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // ablation: no main loop, epilogue only
+    const int NC = CONV_STUDY(a, CONV_ABL_NO_MAINLOOP) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // study builds: epilogue only
     const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     int xoff[MT], qs[MT];                                     // slab-local pixel / PF position of each tile row
     bool valid[MT];
@@ -454,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
     // study hook (tools/tune_conv.py --wcopies): bits 10-13 of relu = number of back-to-back copies of the packed
     // weights minus one; workgroups spread over the copies (do hot weight lines serialise on few L2 channels?)
-    const size_t wcopy = (size_t)(mtile % (((a.relu >> 10) & 15) + 1)) * (size_t)(a.go.C / 32) * NC * 9 * 4096;
+    const size_t wcopy = (size_t)(mtile % ((CONV_STUDY(a, 15 << CONV_WCOPIES_SHIFT) >> CONV_WCOPIES_SHIFT) + 1)) * (size_t)(a.go.C / 32) * NC * 9 * 4096;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.wpk + wcopy + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
     const int wvoff = lane * 16;
@@ -534,7 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         }
     }
     char* scratch = nullptr;
-    if (PLANES >= 2 && a.resid && !(a.relu & 65536)) {        // slab memory becomes the waves' residual staging (bit 65536: A/B off)
+    if (PLANES >= 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {        // slab memory becomes the waves' residual staging (bit 65536: A/B off)
         __syncthreads();                                      // every wave is done reading pixel fragments
         scratch = smem + wave * 8192;
     }
@@ -543,7 +260,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
 }
 
 // exact largest slab (pixels) over the dense tiles of BM real pixels
-static long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
+long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
     const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
     const int mtiles = (int)((R + BM - 1) / BM);
     const int HW = a.gi.H * a.gi.W;
@@ -580,11 +297,12 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
-    const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : (a.relu & 16384) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
+    const int grid = (a.flags & CONV_XCD_ORDER) ? (mtiles + 7) / 8 * 8 * nblocks : (a.flags & CONV_XCD_RANGES) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+#ifdef WSI_STUDY   // measured-negative result kept for studies (r01: 5-25 % slower than slab3)
 // --------------------------------------------------------------------------------------------
 // Streamed form of the dense slab kernel: a PERSISTENT workgroup walks tiles blockIdx.x, +gridDim.x, ...
 // and treats (tile, 128-byte line) pairs as one stream of work items.  Two slab buffers: while item i
@@ -740,28 +458,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(Con
     }
 }
 
-// one (pixel tile, channel tile, 32-channel line, tap) step of every precision mode
-template <int PLANES>
-static __device__ __forceinline__ void mfma_step(f32x16& d, const bf16x8 (&w)[4], const bf16x8 (&x)[4]) {
-    if constexpr (PLANES == 3) {
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
-        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                            __builtin_bit_cast(i32x4, x[3])[0]);
-    } else if constexpr (PLANES == 2) {
-        d = mfma_bf16(w[2], x[0], d);
-        d = mfma_bf16(w[3], x[1], d);
-        d = mfma_bf16(w[0], x[2], d);
-        d = mfma_bf16(w[1], x[3], d);
-        d = mfma_bf16(w[0], x[0], d);
-        d = mfma_bf16(w[1], x[1], d);
-    } else {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
-    }
-}
+#endif  // WSI_STUDY
 
 // --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
@@ -787,7 +484,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     const int l31 = lane & 31, h = lane >> 5;
     const int nblocks = a.go.C / (NTILES * 32);
     int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
-    if (a.relu & 16384) {                                      // XCD-contiguous tile ranges (see conv3x3s1_slab3_kernel)
+    if (a.flags & CONV_XCD_RANGES) {                           // XCD-contiguous tile ranges (see conv3x3s1_slab3_kernel)
         const int chunk = gridDim.x >> 3, lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
         nb = lin % nblocks;
         mtile = lin / nblocks;
@@ -896,7 +593,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         }
     }
     char* scratch = nullptr;
-    if (PLANES >= 2 && a.resid && !(a.relu & 65536)) {        // slab memory becomes the waves' residual staging (epilogues)
+    if (PLANES >= 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {        // slab memory becomes the waves' residual staging (epilogues)
         __syncthreads();
         scratch = xl + wave * 8192;
     }
@@ -908,6 +605,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     }
 }
 
+#ifdef WSI_STUDY   // measured-negative result kept for studies (r01: 5-10 % slower than the wide kernel)
 // --------------------------------------------------------------------------------------------
 // "Wide", fully asynchronous form: ONE workgroup per CU (one wave per SIMD, up to 512 registers each), every
 // global byte arrives by LDS-DMA and is double- (slab) or quadruple- (weights) buffered, so no MFMA ever waits on
@@ -1110,6 +808,8 @@ static int launch_wide2(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+#endif  // WSI_STUDY
+
 template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
 static int launch_wide(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * 128, NTHREADS = WM * WN * 64, BN = WN * NT * 32;
@@ -1124,11 +824,12 @@ static int launch_wide(const ConvArgs& a, hipStream_t st) {
     auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return WSI_EINVAL;
-    const int grid = (a.relu & 16384) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
+    const int grid = (a.flags & CONV_XCD_RANGES) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+#ifdef WSI_STUDY   // launcher of the streamed kernel
 static int g_num_cus = 0;
 template <int MT, int WM, int WN, int PLANES, int MINW>
 static int launch_stream(const ConvArgs& a, hipStream_t st) {
@@ -1169,6 +870,8 @@ static int launch_stream(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
+#endif  // WSI_STUDY
+
 // --------------------------------------------------------------------------------------------
 // Stride-2 3x3 conv (+ fused 1x1 stride-2 downsample) in slab form.
 // in(2y+kh-1, 2x+kw-1) = phase image I[py][px](y+dy, x+dx) with (py,dy) = (1,-1),(0,0),(1,0) for
@@ -1193,7 +896,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     const int l31 = lane & 31, h = lane >> 5;
     const int nblocks = a.go.C / (WN * 32);
     int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
-    if (a.relu & 512) {                                       // XCD-aware order, see conv3x3s1_slab3_kernel
+    if (a.flags & CONV_XCD_ORDER) {                            // XCD-aware order, see conv3x3s1_slab3_kernel
         const int per = 8 * nblocks, r = blockIdx.x % per;
         nb = r >> 3;
         mtile = (blockIdx.x / per) * 8 + (r & 7);
@@ -1354,7 +1057,7 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
     }
-    const int grid = (a.relu & 512) ? (mtiles + 7) / 8 * 8 * nblocks : mtiles * nblocks;
+    const int grid = (a.flags & CONV_XCD_ORDER) ? (mtiles + 7) / 8 * 8 * nblocks : mtiles * nblocks;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
@@ -1555,14 +1258,14 @@ static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
 
 int g_s2_ablate = 0;
 int g_xcd_ranges = 2;                                    // XCD-contiguous tile ranges: 1 = the 64-channel layer only, 2 = every stride-1 layer (r01: ~-1 % overall)
-int g_xcd_order = 0;                                     // 1: ConvArgs.relu |= 512 for multi-channel-block launches
+int g_xcd_order = 0;                                     // 1: CONV_XCD_ORDER for multi-channel-block launches
 int g_s2_small_tiles = 1;                                // r01: 64-pixel tiles measured ~10 % faster (3 workgroups per CU)
 // stride-2 3x3 (+ optional fused downsample) dispatch; cfg 0 = gather kernel (unfused only)
 int wsi_s2_dispatch(const ConvArgs& a_in, int planes, hipStream_t st) {
     ConvArgs a = a_in;
     if (a.in_split_pixels)                                   // phase-split input: the wide kernel is the only reader
         return planes == 3 ? launch_s2wide<3>(a, st) : planes == 2 ? launch_s2wide<2>(a, st) : WSI_EINVAL;
-    if (g_xcd_order && a.go.C > 128) a.relu |= 512;
+    if (g_xcd_order && a.go.C > 128) a.flags |= CONV_XCD_ORDER;
     if (a.gi.C % 64 || a.go.C % 128 || planes < 1 || planes > 3) return WSI_EINVAL;
     if (a.go.H * 2 != a.gi.H || a.go.W * 2 != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;
     const bool fuse = a.out2 != nullptr;
@@ -1572,7 +1275,9 @@ int wsi_s2_dispatch(const ConvArgs& a_in, int planes, hipStream_t st) {
         if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 2, true, 130>(a, st) : launch_s2slab<2, 1, 4, 2, 2, false, 130>(a, st);
         return WSI_EINVAL;                                   // speed mode: gather kernel
     }
-    if (g_s2_ablate && planes == 3 && fuse) return launch_s2slab<2, 1, 4, 3, 3, true, 34, 16>(a, st);   // study build
+#ifdef WSI_STUDY
+    if (g_s2_ablate && planes == 3 && fuse) return launch_s2slab<2, 1, 4, 3, 3, true, 34, 16>(a, st);   // weight loads off (wrong results)
+#endif
     if (g_s2_small_tiles) {                                  // 64-pixel tiles: smaller slabs, more workgroups per CU
         if (planes == 3) return fuse ? launch_s2slab<2, 1, 4, 3, 3, true>(a, st) : launch_s2slab<2, 1, 4, 3, 3, false>(a, st);
         if (planes == 2) return fuse ? launch_s2slab<2, 1, 4, 2, 3, true>(a, st) : launch_s2slab<2, 1, 4, 2, 3, false>(a, st);
@@ -1625,12 +1330,16 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(45, 2, 2, 4, 3) \
     X(46, 4, 1, 2, 3)
 
+int wsi_pp_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);      // conv_pp.hip
+
 int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
     ConvArgs a = a_in;
-    if (g_xcd_order && cfg >= 20 && cfg < 40 && !(a.relu & ~3)) a.relu |= 512;     // slab3 family only
-    if (g_xcd_ranges && !(a.relu & ~3) && ((cfg >= 20 && cfg < 40) || cfg == 60) && (g_xcd_ranges == 2 || a.go.C == 64)) a.relu |= 16384;
+    if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
+    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || (cfg >= 70 && cfg < 80)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
+    if (cfg >= 70 && cfg < 80) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
+#ifdef WSI_STUDY
     if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
     if (cfg == 67) return planes == 3 ? launch_wide<3, 1, 0, 4, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 1, 0, 4, 2, 1>(a, st) : WSI_EINVAL;   // 512 px x 64 couts
     if (cfg == 68) return planes == 3 ? launch_wide<3, 2, 0, 2, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 2, 0, 2, 2, 1>(a, st) : WSI_EINVAL;   // 256 px x 64 couts
@@ -1657,20 +1366,27 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
                   : planes == 2 ? launch_stream<MT, WM, WN, 2, MINW>(a, st) : launch_stream<MT, WM, WN, 1, MINW>(a, st);
         STREAM_CFGS(X)
 #undef X
-
 #define X(id, MT, WM, WN, MINW, DENSE) \
     case id: return planes == 3 ? launch_slab3<MT, WM, WN, 3, MINW, DENSE>(a, st) \
                   : planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);
         SLAB3_CFGS(X)
 #undef X
     }
+#else
+    // product build: only the tuned configurations are instantiated (cfg 30 / 31: slab3 for 128-multiple / 64-channel outputs)
+    if (cfg == 30) return planes == 3 ? launch_slab3<4, 1, 4, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 1, 4, 2, 2, true>(a, st) : launch_slab3<4, 1, 4, 1, 2, true>(a, st);
+    if (cfg == 31) return planes == 3 ? launch_slab3<4, 2, 2, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 2, 2, 2, 2, true>(a, st) : launch_slab3<4, 2, 2, 1, 2, true>(a, st);
+#endif
     return WSI_EINVAL;
 }
 
 // default config per layer shape (tuned on MI355X, tools/tune_conv.py)
 int g_wide_min_c = 128;                                  // channel count from which the wide kernel (cfg 60) is the default
                                                          // (r01: 3-8 % faster than cfg 30 on layers 2-4; A/B via wsi_conv_set_mode)
-static int slab_default_cfg(const ConvArgs& a, int planes) {                          // r01 tune: profiles/r01_tune_conv*.log
+static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {           // r01 / r02 tunes: profiles/r0*_tune_conv*.log
+    // 256-multiple outputs (layers 3-4): the 8-wave ping-pong kernel (r02: +1...4 % over the wide kernel in mx, +4...7 % over
+    // slab3 in single-pass bf16; bit-identical).  It needs two slabs in LDS: maps wider than 33 fall back.
+    if (!fallback && planes != 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
     if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
     return a.go.C % 128 == 0 ? 30 : 31;
 }
@@ -1682,7 +1398,9 @@ int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     if (planes == 3 && !(a.ksize == 3 && a.stride == 1)) return WSI_EINVAL;      // mode 3: slab kernels only
     if (a.ksize == 3 && a.stride == 1) {
         if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;
-        return wsi_slab_dispatch_cfg(a, planes, cfg < 0 ? slab_default_cfg(a, planes) : cfg, st);
+        if (cfg >= 0) return wsi_slab_dispatch_cfg(a, planes, cfg, st);
+        const int rc = wsi_slab_dispatch_cfg(a, planes, slab_default_cfg(a, planes, false), st);
+        return rc != WSI_EINVAL ? rc : wsi_slab_dispatch_cfg(a, planes, slab_default_cfg(a, planes, true), st);
     }
     if ((a.ksize == 3 || a.ksize == 1) && (a.stride == 1 || a.stride == 2)) {
         if (a.go.H * a.stride != a.gi.H || a.go.W * a.stride != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;

@@ -66,6 +66,17 @@ SIGNATURES = {
     'wsi_stitch_add': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_stitch_add_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_softmax_threshold_argmax': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'wsi_resize_bilinear_f64': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    'wsi_argmax_classes': (_i, [_vp, _i, _ll, _vp, _vp]),
+    'wsi_morph_rect': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'wsi_bwperim': (_i, [_vp, _vp, _i, _i, _vp]),
+    'wsi_tumor_bed_workspace_bytes': (_sz, [_i, _i]),
+    'wsi_convex_hull_image': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'wsi_tumor_bed': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'wsi_hull_polygon': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    'wsi_mask_iou_counts': (_i, [_vp, _vp, _ll, _vp, _vp]),
+    'wsi_score_counts': (_i, [_vp, _vp, _vp, _ll, _vp, _vp]),
+    'wsi_esp': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
 }
 
 
