@@ -129,6 +129,65 @@ def main():
                         fmap_sub=f[:, ::16].numpy())
     print('tile logits', logits.shape, float(logits.abs().max()))
 
+    # ---- precision-margin families (r02): checkpoints / inputs far from the default fixture family, 256x256 tiles through
+    #      reference trunk + reference Classifier.  'wide*': per-channel conv scales x0.1..x3.2, BN gamma in [0.25, 3], beta
+    #      N(0, 0.5^2), BN running statistics CALIBRATED by the reference model itself (train-mode forward with momentum 1 on
+    #      a seeded calibration batch) and stored in the fixture; 'hot': classifier scaled so |logit| >= 10; '*_he': H&E-like
+    #      input with saturated 255 background.
+    def tile_logits_ref(net_, cls_, u8_):
+        with torch.no_grad():
+            f_ = net_.maxpool(net_.relu(net_.bn1(net_.conv1(normalize_u8(u8_)))))
+            return cls_(net_.layer4(net_.layer3(net_.layer2(net_.layer1(f_)))))
+
+    fam = {}
+    for tag, wseed, cal_seed, he_calib in (('wide_a', 101, 102, False), ('wide_b', 111, 112, True)):
+        netw = rs.resnet18(False)
+        sdw = W.make_wide_resnet18_state_dict(wseed)
+        full = dict(netw.state_dict())
+        full.update(sdw)
+        netw.load_state_dict(full)
+        for mmod in netw.modules():
+            if isinstance(mmod, torch.nn.BatchNorm2d):
+                mmod.momentum = 1.0                                   # running stats := batch stats of the calibration batch
+        netw.train()
+        cal = W.make_he_patches(cal_seed, 12) if he_calib else W.make_u8_patches(cal_seed, (12, 3, 256, 256))
+        with torch.no_grad():
+            xcal = normalize_u8(cal)
+            fcal = netw.maxpool(netw.relu(netw.bn1(netw.conv1(xcal))))
+            netw.layer4(netw.layer3(netw.layer2(netw.layer1(fcal))))
+        netw.eval()
+        stats = {k: v.numpy().copy() for k, v in netw.state_dict().items() if k.endswith('running_mean') or k.endswith('running_var')}
+        vmin = min(float(v.min()) for k, v in stats.items() if k.endswith('var'))
+        vmax = max(float(v.max()) for k, v in stats.items() if k.endswith('var'))
+        fam[tag] = (netw, wseed, stats)
+        print(tag, 'calibrated BN running_var range [%.3g, %.3g]' % (vmin, vmax))
+    cls_hot = mm.Classifier(512, 4)
+    hot_sd = W.make_head_state_dict(24, 'classifier')
+    cases = []
+    # (case, net, weight family, head seed, head gain, input kind, input seed)
+    for case, tagw, gain, kind, iseed in (('wide_a_uniform', 'wide_a', 1.0, 'uniform', 131), ('wide_a_he', 'wide_a', 1.0, 'he', 132),
+                                          ('wide_b_he_hot', 'wide_b', None, 'he', 133), ('default_he', None, 1.0, 'he', 134),
+                                          ('default_uniform_hot', None, None, 'uniform', 135)):
+        netc = fam[tagw][0] if tagw else net
+        u8c = W.make_he_patches(iseed, 8) if kind == 'he' else W.make_u8_patches(iseed, (8, 3, 256, 256))
+        head = mm.Classifier(512, 4)
+        hsd = {k: v.clone() for k, v in hot_sd.items()}
+        if gain is None:                                               # scale the head until the largest |logit| is 16
+            head.load_state_dict(hsd)
+            with torch.no_grad():
+                g0 = float(tile_logits_ref(netc, head.eval(), u8c).abs().max())
+            gain = 16.0 / g0
+        hsd['fc.0.weight'] *= gain
+        hsd['fc.0.bias'] *= gain
+        head.load_state_dict(hsd)
+        lg = tile_logits_ref(netc, head.eval(), u8c).numpy()
+        rec = dict(weight_family=tagw or 'default', weight_seed=fam[tagw][1] if tagw else 11, head_seed=24, head_gain=np.float64(gain),
+                   input_kind=kind, input_seed=iseed, logits=lg)
+        if tagw:
+            rec.update({'bn__' + k.replace('.', '__'): v for k, v in fam[tagw][2].items()})
+        np.savez_compressed(os.path.join(OUT, 'margin_%s.npz' % case), **rec)
+        print('margin case', case, 'max |logit| %.2f' % float(np.abs(lg).max()))
+
     # ---- contour_ordering.evenly_spaced_points_on_a_contour ------------------------------------
     t = np.linspace(0, 2 * np.pi, 97)
     contour = np.stack((40 + 30 * np.cos(t) + 3 * np.sin(5 * t), 35 + 20 * np.sin(t)), 1)

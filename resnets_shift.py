@@ -52,7 +52,7 @@ class ResNet(nn.Module):
     """forward(xs: (B,P,3,H,W)) -> (per-patch logits (P*B,4) patch-major, ensemble logits (B,4))."""
 
     def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
-                 norm_layer=None, precision='mx'):
+                 norm_layer=None, precision='auto'):
         super().__init__()
         if block is not BasicBlock or list(layers) != [2, 2, 2, 2]:
             raise NotImplementedError('the HIP path implements the ResNet-18 configuration used by resnet18()')
@@ -81,8 +81,10 @@ class ResNet(nn.Module):
             for mod in self.modules():
                 if isinstance(mod, BasicBlock):
                     nn.init.zeros_(mod.bn2.weight)
-        # 'parity' (bf16x2 split, 3 MFMA passes, logit error ~3e-5), 'mx' (fp16 + MX-fp4 cross terms, ~5e-4, still
-        # inside the 1e-3 contract, ~1.3x faster) or 'speed' (single bf16, ~2e-2, outside the contract)
+        # 'auto' (default: mx unless a two-mode probe of the first batch shows its logits more than 4e-4 from parity mode:
+        # engine.AutoTrunkEngine), 'parity' (bf16x2 split, 3 MFMA passes, logit error ~3e-5), 'mx' (fp16 + MX-fp4 cross
+        # terms, ~3e-4 at |logit| <= 5, grows with the logit scale, ~1.35x faster) or 'speed' (single bf16, ~2e-2, outside
+        # the 1e-3 contract)
         self.precision = precision
         self._engine = None
         self._engine_sig = None
@@ -100,13 +102,16 @@ class ResNet(nn.Module):
     # ------------------------------------------------------------------ HIP engine plumbing
     def hip_engine(self, device=None):
         """TrunkEngine over the current parameters (rebuilt when they change or move)."""
-        from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+        from wsi_segmentation_pipeline_amd.engine import AutoTrunkEngine, TrunkEngine
         device = torch.device(device) if device is not None else self.conv1.weight.device
         sig = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters()) \
             + tuple((b.data_ptr(), b._version) for b in self.buffers())
         if self._engine is None or sig != self._engine_sig:
-            self._engine = TrunkEngine(self.state_dict(), device, planes={'parity': 2, 'mx': 3, 'speed': 1}[self.precision],
-                                       head=(self.fc0.weight, self.fc0.bias))
+            if self.precision == 'auto':
+                self._engine = AutoTrunkEngine(self.state_dict(), device, head=(self.fc0.weight, self.fc0.bias))
+            else:
+                self._engine = TrunkEngine(self.state_dict(), device, planes={'parity': 2, 'mx': 3, 'speed': 1}[self.precision],
+                                           head=(self.fc0.weight, self.fc0.bias))
             self._engine_sig = sig
         return self._engine
 

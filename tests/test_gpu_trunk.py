@@ -242,18 +242,15 @@ def test_trunk_set_chunks_equals_unchunked(dev, sd, planes):
         return ([t.clone() for t in eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=True, fmap=True)] +
                 [t.clone() for t in eng.forward_f32(x, feat=True, logits=True, fmap=True)])
     base = run()
+    tol = {1: 2e-2, 2: 2e-4, 3: 2e-3}[planes]                 # another kernel = another summation order (and, in mx, requantisation)
     try:
-        native.check(lib.wsi_conv_set_mode(1 + 128), 'wsi_conv_set_mode')
-        base_nosplit = run()
-        for a, b in zip(base, base_nosplit):
-            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
         for cs, c1 in ((2, 4), (1, 1), (3, 0), (0, 2), (7, 7), (1, 7)):
-            native.check(lib.wsi_conv_set_mode(1), 'wsi_conv_set_mode')
             native.check(lib.wsi_trunk_set_chunks(cs, c1), 'wsi_trunk_set_chunks')
-            want = base if (c1 == 0 or c1 >= 7) else base_nosplit
-            for a, b in zip(run(), want):
-                assert torch.equal(a, b), (planes, cs, c1)
+            for a, b in zip(run(), base):
+                if c1 == 0 or c1 >= 7:                        # same kernels on every stage: bit-identical
+                    assert torch.equal(a, b), (planes, cs, c1)
+                else:                                         # stage 1 hands over ordinary PF: phase-slab instead of wide stride-2 kernel
+                    assert float((a - b).abs().max()) <= tol * float(b.abs().max()), (planes, cs, c1)
     finally:
         lib.wsi_trunk_set_chunks(0, 0)
-        lib.wsi_conv_set_mode(1)
     assert lib.wsi_trunk_set_chunks(2, 3) != 0                    # layer1 chunk must be a multiple of the stem chunk

@@ -12,6 +12,7 @@ from . import native
 
 BN_EPS = 1e-5                                   # nn.BatchNorm2d default (reference resnets_shift.py:117)
 PARITY, SPEED, MX = 2, 1, 3                     # planes: bf16x2 split (3 passes) / single bf16 / fp16 + MX-fp4 cross terms
+AUTO = 'auto'                                   # AutoTrunkEngine: mx unless a two-mode probe of the first batch says parity
 
 
 def _np_ptr(a):
@@ -250,6 +251,96 @@ class TrunkEngine:
         native.check(self.lib.wsi_linear(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), x.shape[0], x.shape[1],
                                          weight.shape[0], int(relu), _stream()), 'wsi_linear')
         return y
+
+
+class AutoTrunkEngine:
+    """TrunkEngine that picks its precision mode per checkpoint AND data, so a caller cannot silently leave the 1e-3 logit
+    contract (BASELINE.json north_star).  mx (fp16 + MX-fp4 cross terms) is ~1.35x faster than parity (bf16x2 split) but
+    its logit error scales with the logit magnitude (2-5e-4 at |logit| ~ 1.5-5, ~4e-3 at |logit| ~ 16: measured against
+    reference goldens, tests/test_gpu_margin.py); parity is 10-20x more accurate.  So:
+      * at load: the folded weights must be representable (finite, inside the fp16 range) or mx is refused outright;
+      * on the first batch: up to `probe` images run in BOTH modes; |mx - parity| (= mx's own error to ~10 %) on the head
+        logits - or, without a head, on the pooled features relative to their size - decides: mx if <= `tol`
+        (default 4e-4: 2.5x inside the contract), parity otherwise.  The decision and the measured value are kept in
+        `.report` and the probe is repeated when the head changes."""
+
+    def __init__(self, state_dict, device, head=None, tol=4e-4, probe=32, **kw):
+        self._kw = dict(kw)
+        self._sd, self._dev, self.tol, self.probe = state_dict, device, float(tol), int(probe)
+        self.report = {'mode': None, 'reason': 'not probed yet', 'probe_error': None}
+        self._par = TrunkEngine(state_dict, device, planes=PARITY, head=head, **kw)
+        self._mx = None
+        reason = self._static_check(state_dict)
+        if reason is None:
+            self._mx = TrunkEngine(state_dict, device, planes=MX, head=head, **kw)
+        else:
+            self.report = {'mode': 'parity', 'reason': reason, 'probe_error': None}
+        self._chosen = None if self._mx is not None else self._par
+
+    @staticmethod
+    def _static_check(sd):
+        """mx needs every BN-folded conv weight finite and well inside the fp16 range."""
+        for key, w in sd.items():
+            if not key.endswith('.weight') or getattr(w, 'dim', lambda: 0)() != 4:
+                continue
+            bn = key.replace('conv1.weight', 'bn1.weight').replace('conv2.weight', 'bn2.weight').replace('downsample.0.weight', 'downsample.1.weight')
+            scale = 1.0
+            if bn != key and bn in sd:
+                var = sd[bn.replace('.weight', '.running_var')].detach().to('cpu', torch.float64)
+                scale = (sd[bn].detach().to('cpu', torch.float64) / torch.sqrt(var + BN_EPS)).abs().max().item()
+            m = float(w.detach().abs().max()) * scale
+            if not np.isfinite(m) or m > 3.0e4:
+                return 'folded weights of %s reach %.3g (outside the fp16 range of the mx mode)' % (key, m)
+        return None
+
+    # the TrunkEngine surface
+    @property
+    def planes(self):
+        return (self._chosen or self._mx or self._par).planes
+
+    @property
+    def head_k(self):
+        return self._par.head_k
+
+    @property
+    def lut(self):
+        return self._par.lut
+
+    def set_head(self, head):
+        self._par.set_head(head)
+        if self._mx is not None:
+            self._mx.set_head(head)
+            self._chosen = None                               # a new head changes the logit scale: probe again
+
+    def linear(self, *a, **k):
+        return self._par.linear(*a, **k)
+
+    def _decide(self, run):
+        """run(engine) -> (feat, logits, fmap) on the probe images, feat and logits requested where possible."""
+        if self._chosen is not None:
+            return
+        fm, lm, _ = run(self._mx)
+        fp, lp, _ = run(self._par)
+        if lm is not None:
+            err, what = float((lm - lp).abs().max()), 'max |logit_mx - logit_parity|'
+        else:
+            err, what = float((fm - fp).abs().max() / fp.abs().max().clamp_min(1e-30)) * 2.0, '2 x max |feat_mx - feat_parity| / max |feat|'
+        ok = np.isfinite(err) and err <= self.tol
+        self._chosen = self._mx if ok else self._par
+        self.report = {'mode': 'mx' if ok else 'parity', 'probe_error': err,
+                       'reason': '%s = %.2e %s tol %.1e on %d probe images' % (what, err, '<=' if ok else '>', self.tol, int(fp.shape[0]))}
+
+    def forward_f32(self, x, feat=False, logits=False, fmap=False, tap=None):
+        if self._chosen is None:
+            n = min(self.probe, x.shape[0])
+            self._decide(lambda e: e.forward_f32(x[:n], feat=True, logits=bool(e.head_k)))
+        return self._chosen.forward_f32(x, feat=feat, logits=logits, fmap=fmap, tap=tap)
+
+    def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
+        if self._chosen is None:
+            n = min(self.probe, tile_xy.shape[0])
+            self._decide(lambda e: e.forward_tiles(slide_u8, tile_xy[:n], ph, pw, feat=True, logits=bool(e.head_k)))
+        return self._chosen.forward_tiles(slide_u8, tile_xy, ph, pw, feat=feat, logits=logits, fmap=fmap, tap=tap)
 
 
 # ---------------------------------------------------------------------- standalone device ops

@@ -107,3 +107,52 @@ def make_u8_patches(seed, shape):
     """i.i.d. uniform u8 patches, e.g. shape (B, P, 3, H, W) planar or (N, H, W, 3) interleaved."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.integers(0, 256, size=shape, dtype=np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------- wider checkpoint families
+def make_wide_resnet18_state_dict(seed, bn_stats=None):
+    """A "trained-like" checkpoint family far from the default one (tests of the precision-mode margin): every conv output
+    channel is scaled by a random factor (x 0.1 ... x 3.2, so BatchNorm's running variance spans ~[0.01, 10] of its usual
+    size), BN gamma is uniform in [0.25, 3] and beta ~ N(0, 0.5^2).  The running statistics must then MATCH the data (as in
+    any trained network: otherwise activations explode through the eight blocks): they are calibrated once with the
+    reference model itself (oracle/gen_golden.py) and travel inside the golden fixture; pass them as
+    bn_stats = {'<bn prefix>.running_mean': array, '<bn prefix>.running_var': array}."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for key, shape, kind in resnet18_key_shapes():
+        if key.startswith('fc.'):
+            continue
+        v = np.asarray(_fill(rng, shape, kind))
+        if kind == 'conv':
+            v = v * np.exp(rng.uniform(np.log(0.1), np.log(3.2), (shape[0], 1, 1, 1))).astype(np.float32)
+        elif kind == 'bn_w':
+            v = rng.uniform(0.25, 3.0, shape).astype(np.float32)
+        elif kind == 'bn_b':
+            v = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(v))
+    if bn_stats is not None:
+        for k, v in bn_stats.items():
+            assert k in sd and tuple(sd[k].shape) == tuple(np.asarray(v).shape), k
+            sd[k] = torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32)))
+    return sd
+
+
+def make_he_patches(seed, n, size=256):
+    """H&E-like u8 tiles (N,3,H,W): saturated white background (255), pink stroma, purple nuclei blobs, mild noise - the
+    input family a real slide gives (large flat 255 areas, strongly correlated channels), unlike i.i.d. uniform noise."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.mgrid[:size, :size].astype(np.float32)
+    out = np.empty((n, 3, size, size), np.uint8)
+    for i in range(n):
+        img = np.full((size, size, 3), 255.0, np.float32)
+        tissue = np.zeros((size, size), bool)
+        for _ in range(int(rng.integers(1, 4))):                       # stroma regions
+            cy, cx, ry, rx = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(40, 160), rng.uniform(40, 160)
+            tissue |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+        img[tissue] = np.array([232, 160, 200], np.float32) + rng.normal(0, 12, (int(tissue.sum()), 3))
+        for _ in range(int(rng.integers(20, 120))):                    # nuclei
+            cy, cx, r = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(2, 7)
+            m = ((yy - cy) ** 2 + (xx - cx) ** 2 < r * r) & tissue
+            img[m] = np.array([90, 50, 140], np.float32) + rng.normal(0, 10, (int(m.sum()), 3))
+        out[i] = np.clip(np.rint(img), 0, 255).astype(np.uint8).transpose(2, 0, 1)
+    return out
