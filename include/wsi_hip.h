@@ -218,6 +218,35 @@ int wsi_score_counts(const uint8_t* p, const uint8_t* gt, const uint8_t* mask, l
                      void* stream);
 int wsi_esp(const double* pts_xy, int n, int num_pts, double* out_xy, double* scratch, void* stream);
 
+/* ---- U-Net decoder: the dense 'seg' path (utils/eval.py:51 `model(batch_image)`, :196-200 `model.decoder(model.encoder(x))`) ----
+ * The reference drives segmentation_models_pytorch's Unet('resnet18') here (eval_tumorbed.py:21-28): third-party, absent and
+ * un-pinned, so the architecture is restated from the published 0.0.x source (parity unpinned):
+ * encoder maps [x4 512 ch /32, x3 256 /16, x2 128 /8, x1 64 /4, x0 64 /2 (conv1+bn1+relu before the max pool)]; five decoder
+ * blocks L = 1..5: nearest x2 upsample, concat the next skip, 2 x (conv3x3 + BN + ReLU) to 256/128/64/32/16 channels;
+ * final_conv 1x1 to `classes`.  Decoder convs are prepacked with wsi_prepack_conv (k = 3) on channel counts padded to
+ * multiples of 64 (zero weights in the padding): conv index 2(L-1)+J, cin = {768,256, 384,128, 192,64, 128,64, 64,64},
+ * cout = {256,256, 128,128, 64,64, 64,64, 64,64}; head_w [classes][head_cin] fp32 with head_cin = 16.
+ * wsi_unet_forward: stem + trunk + decoder for n patches (inputs as wsi_trunk_forward); logits_out [n][classes][h][w] fp32 and /
+ *   or enc_out[5] = the five encoder maps as fp32 NCHW (either may be NULL).  Workspace: wsi_unet_workspace_bytes, zero-filled
+ *   once by wsi_unet_workspace_init; workspace_n as in wsi_trunk_forward.
+ * wsi_unet_decoder: the decoder alone on caller-held fp32 NCHW encoder maps (same workspace). */
+typedef struct {
+    const void* conv_w[10]; const float* conv_b[10];
+    int cin[10], cout[10];
+    const float* head_w; const float* head_b;
+    int head_cin, classes;
+} wsi_unet_decoder_weights;
+size_t wsi_unet_workspace_bytes(const wsi_unet_decoder_weights* dw, int n, int h, int w, int planes);
+int wsi_unet_workspace_init(const wsi_unet_decoder_weights* dw, void* workspace, int n, int h, int w, int planes, void* stream);
+int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights* dw, const float* in_f32, const uint8_t* slide,
+                     long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut, int n, int h,
+                     int w, void* workspace, int workspace_n, float* logits_out, float* enc_out[5], void* stream);
+int wsi_unet_decoder(const wsi_unet_decoder_weights* dw, const float* const enc_nchw[5], int n, int h, int w, int planes,
+                     void* workspace, int workspace_n, float* logits_out, void* stream);
+/* F.interpolate(pred_src, (tile_h * r, tile_w * r)) of utils/eval.py:202-206 (default mode 'nearest') on planes_n
+ * contiguous fp32 (hs, ws) planes */
+int wsi_resize_nearest_f32(const float* src, long long planes_n, int hs, int ws, float* dst, int hd, int wd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,132 @@
+"""GPU parity of the dense 'seg' model (ResNet-18 encoder + smp-style U-Net decoder on HIP kernels) against the torch-fp32 CPU
+spec oracle/unet_oracle.py.  The decoder belongs to a third-party package the reference only calls (absent, un-pinned):
+parity is unpinned by the reference, the spec is self-authored from the published architecture (oracle/unet_oracle.py header);
+the encoder half is pinned through resnet_oracle.  Tolerances are relative to the largest |logit| of the batch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resnet_oracle as R
+from oracle import unet_oracle as U
+from oracle import weights as W
+from oracle import wsi_oracle as WO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def sd():
+    return W.make_unet_state_dict(7, 4)
+
+
+@pytest.mark.parametrize('planes,tol', [(2, 2e-4), (3, 3e-3), (1, 6e-2)])
+def test_unet_forward_matches_oracle(dev, sd, planes, tol):
+    from wsi_segmentation_pipeline_amd.unet import UNetEngine
+    u8 = W.make_u8_patches(41, (3, 3, 64, 96))
+    x = R.normalize_u8(u8)
+    with torch.no_grad():
+        ref = U.unet_forward(sd, x)
+        enc_sd = {k[8:]: v for k, v in sd.items() if k.startswith('encoder.')}
+        ref_enc = U.encoder(enc_sd, x)
+    eng = UNetEngine(sd, dev, planes=planes)
+    got, enc = eng.forward_f32(x.to(dev), logits=True, enc=True)
+    scale = float(ref.abs().max())
+    err = float((got.cpu() - ref).abs().max()) / scale
+    enc_err = [float((a.cpu() - b).abs().max() / b.abs().max()) for a, b in zip(enc, ref_enc)]
+    print('planes %d: logits rel err %.2e (max |logit| %.1f); encoder maps rel err %s' % (planes, err, scale, ['%.1e' % e for e in enc_err]))
+    assert got.shape == ref.shape == (3, 4, 64, 96)
+    assert err <= tol and max(enc_err) <= tol
+    # decoder alone on the oracle's encoder maps == the generic `model.decoder(model.encoder(x))` calling sequence
+    dec = eng.decode([t.to(dev) for t in ref_enc])
+    assert float((dec.cpu() - ref).abs().max()) / scale <= tol
+    # tiles read from a u8 slide (fused read + transform in the stems) == the f32 path
+    strip = np.ascontiguousarray(u8.transpose(0, 2, 3, 1).reshape(-1, 96, 3))
+    xy = np.stack((np.zeros(3, np.int32), np.arange(3, dtype=np.int32) * 64), 1)
+    t = eng.forward_tiles(torch.from_numpy(strip).to(dev), torch.from_numpy(xy), 64, 96)
+    assert float((t.cpu() - ref).abs().max()) / scale <= tol
+    # argmax agreement of the class maps (what the drivers consume)
+    assert float((got.cpu().argmax(1) != ref.argmax(1)).float().mean()) <= (0.002 if planes >= 2 else 0.05)
+
+
+def test_unet_256_batch_and_module_surface(dev, sd):
+    """256x256 tiles (the bench shape), ragged batches, and the nn.Module surface the reference drives: state-dict round trip,
+    model(x), model.encoder(x) -> five maps deepest first, model.decoder(encoding)."""
+    from wsi_segmentation_pipeline_amd.unet import UNetSeg
+    model = UNetSeg(4)
+    model.load_state_dict(sd, strict=True)
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model = model.cuda().eval()
+    u8 = W.make_he_patches(5, 3, 256)
+    x = R.normalize_u8(u8)
+    with torch.no_grad():
+        ref = U.unet_forward(sd, x)
+        y = model(x.cuda())
+        enc = model.encoder(x.cuda())
+        y2 = model.decoder(enc)
+    scale = float(ref.abs().max())
+    assert [tuple(t.shape[1:]) for t in enc] == [(512, 8, 8), (256, 16, 16), (128, 32, 32), (64, 64, 64), (64, 128, 128)]
+    assert float((y.cpu() - ref).abs().max()) / scale <= 2e-4
+    assert float((y2.cpu() - ref).abs().max()) / scale <= 4e-4          # (encoder maps went through fp32 and were re-packed)
+    with pytest.raises(RuntimeError):
+        model(x)                                                      # CPU tensor: no fallback
+
+
+def test_predict_tumorbed_seg_and_predict_wsis_with_unet(dev, sd, tmp_path):
+    """The reference's default mode: predict_tumorbed(mode='seg') (decoder blocks stitched at the map's own level) and
+    predict_wsis driving the U-Net, both against the CPU oracle chain (U-Net spec -> float64 stitch -> threshold / heat map,
+    tumour-bed post-process)."""
+    import myargs
+    import utils.dataset as ds
+    import utils.eval as val
+    from oracle import postprocess_oracle as P
+    from wsi_segmentation_pipeline_amd.slide import ArraySlide
+    from wsi_segmentation_pipeline_amd.unet import UNetSeg
+    a = myargs.args
+    a.scan_level, a.scan_resize, a.num_classes, a.class_probs = 2, 1, 4, [0., 0., 0., 0.]
+    a.tile_w = a.tile_h = 64
+    a.tile_stride_w = a.tile_stride_h = 48
+    a.val_save_pth, a.wsi_mask_pth = str(tmp_path / 'out'), str(tmp_path / 'nomask')
+    rng = np.random.default_rng(13)
+    l2 = np.clip(np.kron(rng.integers(60, 250, (7, 9, 3)), np.ones((32, 32, 1))) + rng.integers(-25, 25, (224, 288, 3)), 0, 255).astype(np.uint8)
+    big = np.repeat(np.repeat(l2, 4, 0), 4, 1)
+    slide = ArraySlide([np.repeat(np.repeat(big, 4, 0), 4, 1)[:8, :8], big[:8, :8], l2], [1.0, 4.0, 16.0])   # only level 2 is read
+    slide.level_dimensions = ((288 * 16, 224 * 16), (288 * 4, 224 * 4), (288, 224))
+    slide.name = 'seg.svs'
+    model = UNetSeg(4)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    model.classifier, model.regressor = torch.nn.Identity(), torch.nn.Identity()
+    params = {'ph': 64, 'pw': 64, 'sh': 48, 'sw': 48}
+    dataset = ds.Dataset_wsis({'seg.svs': slide}, params, bs=5)
+    tiles = dataset.wsis['seg.svs']['iterator'].dataset.datalist
+    mask = dataset.wsis['seg.svs']['mask']
+    assert len(tiles) >= 12
+    res = val.predict_tumorbed(model, dataset, 1, mode='seg')['seg.svs']
+    u8 = np.stack([WO.read_tile(l2, x, y, 64, 64) for x, y in tiles]).transpose(0, 3, 1, 2)
+    with torch.no_grad():
+        tp = U.unet_forward(sd, R.normalize_u8(u8)).numpy()
+    pred = WO.stitch_tumorbed(tiles, tp, 4, l2.shape[:2], 1.0, 64, 64)
+    ref_cls, ref_probs = WO.threshold_probs(pred)
+    ref_heat = WO.tumorbed_heatmap(ref_probs, mask, 'seg')
+    flips = float((res['classes'] != ref_cls).mean())
+    dheat = np.abs(res['heatmap'].astype(int) - ref_heat.astype(int))
+    print('seg: class flips %.4f, heat pixels off by > 1: %d of %d' % (flips, int((dheat > 1).sum()), dheat.size))
+    assert flips <= 0.002 and (dheat > 1).mean() <= 0.002            # logits differ by ~1e-4 relative: a few ties may flip
+    assert os.path.exists('%s/1/seg.svs_48_heatmap.png' % a.val_save_pth)
+    # predict_wsis with the same model: accumulate at scan level, argmax, tumour bed
+    dataset = ds.Dataset_wsis({'seg.svs': slide}, params, bs=5)
+    out = val.predict_wsis(model, dataset, 2)['seg.svs']
+    ref_w = WO.stitch_wsis(tiles, tp, 4, l2.shape[:2], 64, 64)
+    assert float(np.abs(out['pred'].cpu().numpy() - ref_w).max()) <= 3e-4 * float(np.abs(ref_w).max())
+    p = out['classes_level2'].cpu().numpy()
+    tb_pred, outline = P.tumor_bed(p)                                # post-process: bit-exact given the device's own class map
+    assert np.array_equal(out['tumor_bed'].cpu().numpy(), tb_pred) and np.array_equal(out['outline'].cpu().numpy(), outline)
+    assert float((p != np.argmax(ref_w, 0)).mean()) <= 0.002

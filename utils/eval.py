@@ -23,7 +23,8 @@ from wsi_segmentation_pipeline_amd import slide as S
 
 class TrunkEncoder(torch.nn.Module):
     """``model.encoder`` surface over a resnets_shift.ResNet: encoder(x) -> [deepest feature map]
-    (the reference indexes ``encoding[0]`` for the 512-channel map, utils/eval.py:196-198)."""
+    (the reference indexes ``encoding[0]`` for the 512-channel map, utils/eval.py:196-198).  The full five-map encoder of
+    the dense 'seg' model is wsi_segmentation_pipeline_amd.unet.UNetEncoder."""
 
     def __init__(self, resnet):
         super().__init__()
@@ -72,9 +73,8 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
     """Tumour-bed heat maps for every slide in ``dataset`` (a utils.dataset.Dataset_wsis).
     Writes <val_save_pth>/<ep>/<key>_<stride>_heatmap.png and _overlay.png (rank 0) and returns
     {key: {'heatmap': u8 (H2,W2) ndarray, 'classes': u8 ndarray, 'logits': (T,C) tensor}}."""
-    if mode != 'cls':
-        raise NotImplementedError("mode='seg' needs the segmentation_models_pytorch U-Net decoder, which is third-party "
-                                  "and absent here (SURVEY.md 8f rank 1); use mode='cls'")
+    if mode not in ('cls', 'seg'):
+        raise ValueError("mode must be 'cls' or 'seg'")
     out_dir = '{}/{}'.format(args.val_save_pth, ep)
     if save and rank == 0:
         os.makedirs(out_dir, exist_ok=True)
@@ -91,12 +91,12 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
             map_hw = scan.level_dimensions[ref_level][::-1]
             m = scan.level_downsamples[args.scan_level] / scan.level_downsamples[ref_level]
             mask = torch.from_numpy(np.ascontiguousarray(entry['mask'])).to(dev) if entry.get('mask') is not None else None
-            if isinstance(model, SlideClassifierModel):
+            if mode == 'cls' and isinstance(model, SlideClassifierModel):
                 # fused fast path: the stem kernel reads the HBM-resident slide directly
                 level = scan.device_level(args.scan_level, dev)
                 r = S.infer_slide_cls(model.fused_engine(dev), level, ds.tile_xy, ds.params.ph, ds.params.pw, m, map_hw,
                                       args.num_classes, args.class_probs, mask, rank, world, want_probs=False)
-            else:
+            elif mode == 'cls':
                 # generic loop over the iterator API (any model exposing .encoder/.classifier on the GPU)
                 pred = torch.zeros((args.num_classes,) + tuple(map_hw), dtype=torch.float64, device=dev)
                 all_logits = []
@@ -107,6 +107,23 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                     all_logits.append(logits)
                 classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'cls', want_probs=False)
                 r = {'logits': torch.cat(all_logits), 'pred': pred, 'classes': classes, 'heatmap': heat}
+            else:
+                # mode 'seg' (the reference's default, utils/eval.py:196-215): pred_src = model.decoder(model.encoder(x)) is a
+                # (B, C, ph, pw) block per tile, optionally nearest-resized to (tile_h * r, tile_w * r), added at int(m * x),
+                # int(m * y) over a (dy, dx) = int(m * ph), int(m * pw) footprint - which therefore has to equal the block size
+                pred = torch.zeros((args.num_classes,) + tuple(map_hw), dtype=torch.float64, device=dev)
+                dy, dx = int(m * ds.params.ph), int(m * ds.params.pw)
+                for batch_x, batch_y, batch_image in it:
+                    pred_src = model.decoder(model.encoder(batch_image.to(dev)))
+                    if args.scan_resize != 1:
+                        pred_src = E.resize_nearest(pred_src, (int(args.tile_h * args.scan_resize), int(args.tile_w * args.scan_resize)))
+                    if tuple(pred_src.shape[2:]) != (dy, dx):
+                        raise ValueError("mode='seg': the decoder output %s does not match the stitch footprint (%d, %d) = int(m * tile); "
+                                         "scan at the map's level or set scan_resize (utils/eval.py:202-215)" % (tuple(pred_src.shape[2:]), dy, dx))
+                    xy = np.stack((batch_x.numpy(), batch_y.numpy()), 1)
+                    E.stitch_add_dense(pred, pred_src, torch.from_numpy(S.map_coords(xy, m)))
+                classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'seg', want_probs=False)
+                r = {'logits': None, 'pred': pred, 'classes': classes, 'heatmap': heat}
             heat = r['heatmap'].cpu().numpy()
             results[key] = {'heatmap': heat, 'classes': r['classes'].cpu().numpy(), 'logits': r['logits']}
             if save and rank == 0:

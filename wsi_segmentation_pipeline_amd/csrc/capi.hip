@@ -25,6 +25,11 @@ int wsi_stitch_add_dense_dispatch(const float* tiles, const int* txy, int T, int
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
                          const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
 
+int wsi_upsample_concat_dispatch(const void* x, const void* skip, void* out, int n, int h, int w, int cx, int cs, int planes, hipStream_t st);
+int wsi_nhwc_to_pf_dispatch(const float* in, void* out, int n, int h, int w, int c, int planes, hipStream_t st);
+int wsi_unet_head_dispatch(const void* in, int n, int h, int w, int c_pf, const float* wt, const float* b, int cin, int k, float* out,
+                           int planes, hipStream_t st);
+int wsi_resize_nearest_dispatch(const float* src, long long planes_n, int hs, int ws, float* dst, int hd, int wd, hipStream_t st);
 int wsi_resize_dispatch(const double* src, int C, int Hs, int Ws, double* dst, int Hd, int Wd, hipStream_t st);
 int wsi_argmax_dispatch(const double* pred, int C, long long HW, uint8_t* classes, hipStream_t st);
 int wsi_threshold_dispatch(const uint8_t* src, long long n, int lo, uint8_t* dst, hipStream_t st);
@@ -645,7 +650,8 @@ int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, v
 // n-1 belong to its own block).
 static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide, long long pitch, int slide_h,
                      int slide_w, const int* tile_xy, const float* lut, int n, int cap, int h, int w, void* workspace,
-                     int stop_after, hipStream_t st, const TrunkPlan& p, size_t& last_off, int& last_stage) {
+                     int stop_after, hipStream_t st, const TrunkPlan& p, size_t& last_off, int& last_stage,
+                     bool allow_split = true, size_t* stage_off = nullptr) {
     char* ws = (char*)workspace;
     const int planes = wt->planes;
     int rc = WSI_OK;
@@ -671,7 +677,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     const int do_l1 = stop_after != 0;
     // stage s writes its output phase-split when the next stage's entry can read it with the wide stride-2 kernel:
     // full runs only (taps unpack ordinary PF), split precision, next output maps <= 33 wide, whole-batch stages
-    auto can_split = [&](int s) { return g_s2_split && g_s2_slab && stop_after >= 8 && planes >= 2 && s < 3 && p.sw[s + 1] <= 33; };
+    auto can_split = [&](int s) { return allow_split && g_s2_split && g_s2_slab && stop_after >= 8 && planes >= 2 && s < 3 && p.sw[s + 1] <= 33; };
     const bool split0 = can_split(0) && c1 >= n;
     int l1_out = 0;                                    // buffer index holding layer1's output
     for (int n1 = 0; n1 < n; n1 += c1) {
@@ -707,6 +713,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
         l1_out = cur;
     }
     last_off = p.buf[0][l1_out]; last_stage = 0;
+    if (stage_off) stage_off[0] = p.buf[0][l1_out];           // (ordinary PF only when allow_split is off)
     if (stop_after >= 0 && stop_after <= 2) return WSI_OK;
 
     int cur = l1_out;
@@ -761,6 +768,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 x_split = false;
             }
             x = out;
+            if (b == 1 && stage_off) stage_off[s] = (size_t)((char*)out - ws);
             ++block;
             last_stage = s;
             if (block == stop_after) return WSI_OK;
@@ -806,6 +814,133 @@ int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, cons
     if (rc) return rc;
     return wsi_pf_unpack((const char*)workspace + off, tap_out_nchw, n, p.sc[stage], p.sh[stage], p.sw[stage], wt->planes,
                          stream);
+}
+
+
+// ------------------------------------------------------------------------------------ U-Net (dense 'seg' path)
+// smp-style decoder on the ResNet-18 trunk: five blocks of [nearest x2 upsample, concat skip, 2 x (3x3 conv + BN + ReLU)]
+// at channels 256/128/64/32/16 (stored padded to 64-multiples: the padding channels carry zero weights), 1x1 head.
+static const int kUnetSkipC[5] = {256, 128, 64, 64, 0};      // encoder maps x3, x2, x1, x0 (and none for the last block)
+struct UnetPlan {
+    size_t x0, cat[5], mid[5], out[5], total;
+    int r_h[5], r_w[5], cx[5];                               // resolution of block L; channels of its upsampled input
+};
+static int unet_plan(const wsi_unet_decoder_weights* dw, int n, int h, int w, int planes, UnetPlan& u) {
+    if (!dw || n <= 0 || h % 32 || w % 32 || planes < 1 || planes > 3) return WSI_EINVAL;
+    size_t off = 0;
+    u.x0 = off; off += align_up(wsi_pf_bytes(n, h / 2, w / 2, 64, planes), 256);
+    int cprev = 512;
+    for (int L = 0; L < 5; ++L) {
+        u.r_h[L] = (h / 16) << L; u.r_w[L] = (w / 16) << L; u.cx[L] = cprev;
+        const int cin = cprev + kUnetSkipC[L], cout = dw->cout[2 * L];
+        if (dw->cin[2 * L] != cin || dw->cin[2 * L + 1] != cout || dw->cout[2 * L + 1] != cout || cout % 64 || cout <= 0) return WSI_EINVAL;
+        u.cat[L] = off; off += align_up(wsi_pf_bytes(n, u.r_h[L], u.r_w[L], cin, planes), 256);
+        u.mid[L] = off; off += align_up(wsi_pf_bytes(n, u.r_h[L], u.r_w[L], cout, planes), 256);
+        u.out[L] = off; off += align_up(wsi_pf_bytes(n, u.r_h[L], u.r_w[L], cout, planes), 256);
+        cprev = cout;
+    }
+    if (dw->head_cin <= 0 || dw->head_cin > cprev || dw->classes <= 0) return WSI_EINVAL;
+    u.total = off;
+    return WSI_OK;
+}
+
+size_t wsi_unet_workspace_bytes(const wsi_unet_decoder_weights* dw, int n, int h, int w, int planes) {
+    UnetPlan u;
+    const size_t t = wsi_trunk_workspace_bytes(n, h, w, planes);
+    return (!t || unet_plan(dw, n, h, w, planes, u)) ? 0 : align_up(t, 256) + u.total;
+}
+
+int wsi_unet_workspace_init(const wsi_unet_decoder_weights* dw, void* workspace, int n, int h, int w, int planes, void* stream) {
+    UnetPlan u;
+    if (!workspace || unet_plan(dw, n, h, w, planes, u)) return WSI_EINVAL;
+    int rc = wsi_trunk_workspace_init(workspace, n, h, w, planes, stream);
+    if (rc) return rc;
+    char* base = (char*)workspace + align_up(wsi_trunk_workspace_bytes(n, h, w, planes), 256);
+    return hipMemsetAsync(base, 0, u.total, (hipStream_t)stream) == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+// the decoder on five PF encoder maps (x4 deepest ... x0 = stem output at half resolution), `dec` = decoder part of the workspace
+static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& u, const void* const enc[5], int n, int planes, char* dec,
+                            float* logits_out, hipStream_t st) {
+    const void* x = enc[0];
+    int rc = WSI_OK;
+    for (int L = 0; L < 5 && !rc; ++L) {
+        const int H = u.r_h[L], W = u.r_w[L], cin = dw->cin[2 * L], cout = dw->cout[2 * L];
+        rc = wsi_upsample_concat_dispatch(x, L < 4 ? enc[L + 1] : nullptr, dec + u.cat[L], n, H / 2, W / 2, u.cx[L], kUnetSkipC[L], planes, st);
+        if (!rc) rc = conv_common(dec + u.cat[L], dec + u.mid[L], nullptr, dw->conv_w[2 * L], dw->conv_b[2 * L], n, H, W, cin, cout, 1, 3, 1, planes, st);
+        if (!rc) rc = conv_common(dec + u.mid[L], dec + u.out[L], nullptr, dw->conv_w[2 * L + 1], dw->conv_b[2 * L + 1], n, H, W, cout, cout, 1, 3, 1, planes, st);
+        x = dec + u.out[L];
+    }
+    if (!rc) rc = wsi_unet_head_dispatch(x, n, u.r_h[4], u.r_w[4], dw->cout[9], dw->head_w, dw->head_b, dw->head_cin, dw->classes, logits_out, planes, st);
+    return rc;
+}
+
+int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights* dw, const float* in_f32, const uint8_t* slide,
+                     long long slide_pitch_bytes, int slide_h, int slide_w, const int* tile_xy, const float* lut, int n, int h,
+                     int w, void* workspace, int workspace_n, float* logits_out, float* enc_out[5], void* stream) {
+    TrunkPlan p;
+    UnetPlan u;
+    const int cap = workspace_n > 0 ? workspace_n : n;
+    if (!wt || !dw || !workspace || n <= 0 || cap < n || (!logits_out && !enc_out) || h % 32 || w % 32) return WSI_EINVAL;
+    if (trunk_plan(cap, h, w, wt->planes, p) || unet_plan(dw, cap, h, w, wt->planes, u)) return WSI_EINVAL;
+    if (!in_f32 && (!slide || !tile_xy || !lut)) return WSI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    char* dec = ws + align_up(p.total, 256);
+    const int planes = wt->planes;
+    // encoder: the trunk with every stage output kept as an ordinary PF tensor (no phase-split hand-over) ...
+    size_t off, stage_off[4];
+    int stage;
+    int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, cap, h, w, workspace, 8, st, p, off, stage,
+                       false, stage_off);
+    if (rc) return rc;
+    // ... plus x0 = relu(bn1(conv1(x))) before the max pool, which the fused stem kernel never writes: the unfused stem
+    // conv (bf16 hi/lo arithmetic) into the fp32 scratch, then PF lines
+    StemArgs a;
+    a.mode = in_f32 ? 0 : 1;
+    a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
+    a.origins = tile_xy; a.lut = lut; a.wpk = wt->stem_w; a.bias = wt->stem_b; a.out = (float*)(ws + p.stem_scratch);
+    a.N = n; a.H = h; a.W = w; a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
+    for (int c = 0; c < 3; ++c) { a.offs[c] = 0.f; a.padv[c] = 0.f; }
+    rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
+    if (!rc) rc = wsi_nhwc_to_pf_dispatch(a.out, dec + u.x0, n, h / 2, w / 2, 64, planes, st);
+    if (rc) return rc;
+    const void* enc[5] = {ws + stage_off[3], ws + stage_off[2], ws + stage_off[1], ws + stage_off[0], dec + u.x0};
+    if (enc_out) {                                           // the `model.encoder(x)` surface: five fp32 NCHW maps, deepest first
+        const int ec[5] = {512, 256, 128, 64, 64};
+        for (int i = 0; i < 5 && !rc; ++i)
+            if (enc_out[i]) rc = wsi_pf_unpack(enc[i], enc_out[i], n, ec[i], i < 4 ? h >> (5 - i) : h / 2, i < 4 ? w >> (5 - i) : w / 2, planes, stream);
+        if (rc) return rc;
+    }
+    return logits_out ? unet_decoder_run(dw, u, enc, n, planes, dec, logits_out, st) : WSI_OK;
+}
+
+int wsi_resize_nearest_f32(const float* src, long long planes_n, int hs, int ws, float* dst, int hd, int wd, void* stream) {
+    if (!src || !dst || src == dst) return WSI_EINVAL;
+    return wsi_resize_nearest_dispatch(src, planes_n, hs, ws, dst, hd, wd, (hipStream_t)stream);
+}
+
+// `model.decoder(encoding)` with caller-held fp32 NCHW maps (deepest first): pack, then the same decoder launches
+int wsi_unet_decoder(const wsi_unet_decoder_weights* dw, const float* const enc_nchw[5], int n, int h, int w, int planes, void* workspace,
+                     int workspace_n, float* logits_out, void* stream) {
+    TrunkPlan p;
+    UnetPlan u;
+    const int cap = workspace_n > 0 ? workspace_n : n;
+    if (!dw || !enc_nchw || !workspace || !logits_out || n <= 0 || cap < n) return WSI_EINVAL;
+    if (trunk_plan(cap, h, w, planes, p) || unet_plan(dw, cap, h, w, planes, u)) return WSI_EINVAL;
+    char* ws = (char*)workspace;
+    char* dec = ws + align_up(p.total, 256);
+    // encoder maps are packed into the trunk part of the workspace (stage buffers 0 of stages 3..0) and x0
+    const int ec[5] = {512, 256, 128, 64, 64};
+    const void* enc[5];
+    int rc = WSI_OK;
+    for (int i = 0; i < 5 && !rc; ++i) {
+        if (!enc_nchw[i]) return WSI_EINVAL;
+        char* dst = i < 4 ? ws + p.buf[3 - i][0] : dec + u.x0;
+        rc = wsi_pf_pack(enc_nchw[i], dst, n, ec[i], i < 4 ? h >> (5 - i) : h / 2, i < 4 ? w >> (5 - i) : w / 2, planes, stream);
+        enc[i] = dst;
+    }
+    return rc ? rc : unet_decoder_run(dw, u, enc, n, planes, dec, logits_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

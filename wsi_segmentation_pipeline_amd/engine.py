@@ -442,6 +442,17 @@ def stitch_add_dense(pred, tile_pred, map_xy):
     return pred
 
 
+def resize_nearest(x, size):
+    """F.interpolate(x, size) in its default 'nearest' mode on a (B,C,H,W) fp32 GPU tensor (reference utils/eval.py:202-206)."""
+    lib = native.load()
+    _require_gpu(x, 'tensor')
+    x = x.to(torch.float32).contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+    native.check(lib.wsi_resize_nearest_f32(_ptr(x), b * c, h, w, _ptr(out), out.shape[2], out.shape[3], _stream()), 'wsi_resize_nearest_f32')
+    return out
+
+
 def softmax_threshold_argmax(pred, class_probs, mask=None, heat_mode=None, want_probs=True):
     """pred (C,H,W) float64 GPU -> (classes u8 (H,W), probs f64 (C,H,W) or None, heat u8 (H,W) or None)."""
     lib = native.load()

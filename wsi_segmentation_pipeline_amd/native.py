@@ -29,6 +29,13 @@ class WsiTrunkWeights(C.Structure):
     ]
 
 
+class WsiUnetDecoderWeights(C.Structure):
+    _fields_ = [
+        ('conv_w', C.c_void_p * 10), ('conv_b', C.c_void_p * 10), ('cin', C.c_int * 10), ('cout', C.c_int * 10),
+        ('head_w', C.c_void_p), ('head_b', C.c_void_p), ('head_cin', C.c_int), ('classes', C.c_int),
+    ]
+
+
 _vp, _i, _ll, _sz, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_float
 # name -> (restype, argtypes); must list every symbol include/wsi_hip.h declares
 SIGNATURES = {
@@ -77,6 +84,12 @@ SIGNATURES = {
     'wsi_mask_iou_counts': (_i, [_vp, _vp, _ll, _vp, _vp]),
     'wsi_score_counts': (_i, [_vp, _vp, _vp, _ll, _vp, _vp]),
     'wsi_esp': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    'wsi_unet_workspace_bytes': (_sz, [C.POINTER(WsiUnetDecoderWeights), _i, _i, _i, _i]),
+    'wsi_unet_workspace_init': (_i, [C.POINTER(WsiUnetDecoderWeights), _vp, _i, _i, _i, _i, _vp]),
+    'wsi_unet_forward': (_i, [C.POINTER(WsiTrunkWeights), C.POINTER(WsiUnetDecoderWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i,
+                              _vp, _i, _vp, C.POINTER(C.c_void_p * 5), _vp]),
+    'wsi_resize_nearest_f32': (_i, [_vp, _ll, _i, _i, _vp, _i, _i, _vp]),
+    'wsi_unet_decoder': (_i, [C.POINTER(WsiUnetDecoderWeights), C.POINTER(C.c_void_p * 5), _i, _i, _i, _i, _vp, _i, _vp, _vp]),
 }
 
 

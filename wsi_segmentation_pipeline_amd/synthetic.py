@@ -156,3 +156,15 @@ def make_he_patches(seed, n, size=256):
             img[m] = np.array([90, 50, 140], np.float32) + rng.normal(0, 10, (int(m.sum()), 3))
         out[i] = np.clip(np.rint(img), 0, 255).astype(np.uint8).transpose(2, 0, 1)
     return out
+
+
+def make_unet_state_dict(seed, classes=4):
+    """Seeded state dict of the U-Net 'seg' model (encoder.* = the ResNet-18 trunk keys of make_resnet18_state_dict(seed),
+    decoder.* per wsi_segmentation_pipeline_amd.unet.decoder_key_shapes), randomised BN statistics as everywhere."""
+    from .unet import decoder_key_shapes
+    sd = {'encoder.' + k: v for k, v in make_resnet18_state_dict(seed, with_fc=False).items()
+          if not k.startswith('fc')}
+    rng = np.random.Generator(np.random.PCG64(seed + 5000))
+    for key, shape, kind in decoder_key_shapes(classes):
+        sd[key] = torch.from_numpy(np.asarray(_fill(rng, shape, kind)))
+    return sd
