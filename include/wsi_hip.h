@@ -184,6 +184,11 @@ int wsi_stitch_add_dense(const float* tile_pred, const int* map_xy, int t, int c
                          int map_w, void* stream);
 int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream);
+/* region paint (scannet.py:154-155, slic.py:98-99): label[pixel_idx[e]] = region_class[region_of[e]] for every entry e, regions
+ * numbered in paint order - where regions overlap the last one wins, as in the reference's loop; label is int64 (np.zeros of
+ * the reference), untouched elsewhere; winner_scratch: npix ints */
+int wsi_paint_regions(const long long* pixel_idx, const int* region_of, long long n, const uint8_t* region_class, int* winner_scratch,
+                      long long* label, long long npix, void* stream);
 
 /* ---- tumour-bed post-process of the stitched map (all device memory; byte / integer / float64 work) ----------
  * Bit-exact against oracle/postprocess_oracle.py, which restates the published algorithms of the third-party calls

@@ -343,3 +343,48 @@ def test_pingpong_conv_equals_wide_kernel(dev, shape):
                     assert torch.equal(out, ref), (shape, planes, cfg, resid is not None, relu)
                     ran += 1
     assert ran > 0 or c < 128 or w > 33                        # (maps wider than 33: two slabs of this tile do not fit)
+
+
+@pytest.mark.parametrize('shape', [(8, 8192, 4096), (70, 8192, 4096), (200, 512, 128), (64, 64, 256), (65, 96, 128)])
+def test_linear_mfma_gemm(dev, shape):
+    """The bag head fc.0 = Linear(8192 -> 4096) + ReLU on the fp32-input MFMA GEMM (exact fp32 products) vs torch fp32 on the CPU;
+    ragged bag counts, with and without bias / ReLU."""
+    import ctypes as C
+    from wsi_segmentation_pipeline_amd import native
+    lib = native.load()
+    b, k, j = shape
+    g = torch.Generator().manual_seed(b + k)
+    x, w, bias = torch.randn(b, k, generator=g), torch.randn(j, k, generator=g) * (1.0 / k ** 0.5), torch.randn(j, generator=g)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
+    for relu, bb in ((1, bd), (0, None)):
+        y = torch.full((b, j), float('nan'), device=dev)
+        native.check(lib.wsi_linear(xd.data_ptr(), wd.data_ptr(), bb.data_ptr() if bb is not None else None, y.data_ptr(), b, k, j, relu, st), 'linear')
+        ref = F.linear(x, w, bias if bb is not None else None)
+        ref = F.relu(ref) if relu else ref
+        assert float((y.cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_paint_regions_last_wins(dev):
+    """wsi_paint_regions == the reference's sequential `pred_mask[foreground_indices] = cls` loop, overlapping regions included."""
+    from wsi_segmentation_pipeline_amd import bags as B
+    rng = np.random.default_rng(3)
+    shape = (97, 131)
+    lists, cls = [], rng.integers(0, 4, 40).astype(np.uint8)
+    for r in range(40):
+        if r % 3 == 0:
+            m = np.zeros(shape, bool)
+            y, x = rng.integers(0, 80), rng.integers(0, 110)
+            m[y:y + rng.integers(1, 30), x:x + rng.integers(1, 30)] = True
+            lists.append(np.nonzero(m))                              # tuple of index arrays, as the reference stores them
+        else:
+            lists.append(rng.integers(0, shape[0] * shape[1], rng.integers(0, 200)))
+    ref = np.zeros(shape, np.int64)
+    for idx, c in zip(lists, cls):
+        if isinstance(idx, tuple):
+            ref[idx] = c
+        else:
+            ref.reshape(-1)[idx] = c
+    got = B.paint_regions(shape, lists, torch.from_numpy(cls).to(dev), dev)
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), ref)
+    assert B.paint_regions(shape, [], torch.zeros(0, dtype=torch.uint8, device=dev), dev).sum().item() == 0

@@ -71,3 +71,56 @@ def test_two_rank_pipeline_equals_single_rank(resident):
     for rank in (0, 1):
         for k in ('logits', 'pred', 'classes', 'heatmap', 'probs'):
             assert np.array_equal(got[rank][k], ref[k].numpy()), (rank, k)
+
+
+# ------------------------------------------------------------------------------ region bags over two ranks (cfg4)
+def _regions(rank, world):
+    import myargs
+    import resnets_shift
+    import utils.eval as val
+    from utils.dataset_hr import GenerateIterator_eval
+    from wsi_segmentation_pipeline_amd import synthetic as W
+    from wsi_segmentation_pipeline_amd.slide import ArraySlide
+    myargs.args.batch_size = 3
+    myargs.args.class_probs = [0., 0., 0., 0.]
+    rng = np.random.default_rng(4)
+    l0 = rng.integers(0, 256, (1024, 1536, 3), dtype=np.uint8)
+    slide = ArraySlide([l0, l0[::4, ::4], l0[::16, ::16]], [1.0, 4.0, 16.0])
+    label_shape = (64, 96)
+    metadata = {}
+    for rid in range(11):
+        ys, xs = np.nonzero(rng.random(label_shape) < 0.02 * (rid + 1))
+        metadata[rid] = {'cnt_xy': rng.integers(8, [88, 56], (10, 2)), 'perim_xy': rng.integers(8, [88, 56], (12, 2)),
+                         'wsipath': 'unused', 'scan_level': 2, 'foreground_indices': (ys, xs), 'tile_id': rid}
+    model = resnets_shift.resnet18(False, precision='parity')
+    model.load_state_dict(W.make_resnet18_state_dict(11))
+    model = model.cuda().eval()
+    it = GenerateIterator_eval(metadata, scan=slide)
+    assert len(it.dataset) == 11
+    return val.predict_regions(model, it, metadata, label_shape, rank=rank, world=world)
+
+
+def _regions_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    q.put((rank, _regions(rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_region_bags_equal_single_rank():
+    """predict_regions with the bags sharded over two ranks (greedy balance, one all-gather of the ensemble logits, device paint
+    on every rank) == the single-rank label image, bit for bit."""
+    ref = _regions(0, 1)
+    assert ref.any()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_regions_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+    assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)

@@ -192,3 +192,47 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
         assert sorted(f for f in os.listdir(d) if f.startswith('rank')) == ['rank0', 'rank1', 'rank2']
         monkeypatch.setenv('STUB_FAIL', '1')
         assert bench.spawn_ranks(3) != 0
+
+
+# ------------------------------------------------------------------------------ region bags across ranks (cfg4)
+def test_shard_bags_balances_and_partitions():
+    from wsi_segmentation_pipeline_amd import bags as B
+    rng = np.random.default_rng(0)
+    for R in (0, 1, 7, 1000):
+        for world in (1, 2, 3, 8):
+            sh = B.shard_bags(np.full(R, 16.0), world)
+            assert sorted(np.concatenate(sh).tolist()) == list(range(R))
+            assert max(len(s) for s in sh) - min(len(s) for s in sh) <= 1
+            assert all(np.all(np.diff(s) > 0) for s in sh)
+    costs = rng.lognormal(2, 1, 500)
+    sh = B.shard_bags(costs, 8)
+    loads = [costs[s].sum() for s in sh]
+    assert max(loads) - min(loads) <= costs.max()                      # LPT: within one item of perfect balance
+
+
+def _bag_gather_worker(rank, world, port, q):
+    from wsi_segmentation_pipeline_amd import bags as B
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    R = 11
+    full = torch.arange(R * 4, dtype=torch.float32).view(R, 4)
+    costs = np.array([5, 1, 9, 2, 2, 7, 3, 3, 8, 1, 4], np.float64)
+    shards = B.shard_bags(costs, world)
+    out = B.gather_rows(full[torch.as_tensor(shards[rank])].clone(), shards, rank, world)
+    q.put((rank, bool(torch.equal(out, full))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bag_logits_gather_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bag_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -56,20 +56,27 @@ class Dataset_eval:
 class DeviceBagIterator:
     """Yields ((B,16,3,64,64) fp32 GPU bags, tile_ids int64 tensor), raster (metadata) order."""
 
-    def __init__(self, dataset, batch_size, device=None):
+    def __init__(self, dataset, batch_size, device=None, indices=None):
         self.dataset, self.batch_size = dataset, int(batch_size)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.indices = None if indices is None else [int(i) for i in indices]     # this rank's shard of the bags (utils.eval.predict_regions)
 
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        n = len(self.dataset) if self.indices is None else len(self.indices)
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def shard(self, indices):
+        """The same producer restricted to a subset of the bags (metadata order kept)."""
+        return DeviceBagIterator(self.dataset, self.batch_size, self.device, indices)
 
     def __iter__(self):
         ds = self.dataset
         level = ds.scan.device_level(HR_SCAN_LEVEL, self.device)
         down = ds.scan.level_downsamples[HR_SCAN_LEVEL]
         lut = torch.from_numpy(E.normalize_lut(args.dataset_mean, args.dataset_std)).to(self.device)
-        for i in range(0, len(ds), self.batch_size):
-            idx = range(i, min(i + self.batch_size, len(ds)))
+        order = list(range(len(ds))) if self.indices is None else self.indices
+        for i in range(0, len(order), self.batch_size):
+            idx = order[i:i + self.batch_size]
             xy = np.concatenate([ds.corners(j) for j in idx])                       # level-0 corners
             lxy = np.floor_divide(xy, int(down)).astype(np.int32) if float(down).is_integer() \
                 else np.floor(xy / down).astype(np.int32)

@@ -235,23 +235,34 @@ def tumor_bed_overlay(heat_u8, thumb_rgb=None):
     return tb, over.to(torch.uint8)
 
 
-def predict_regions(model, iterator, metadata, label_shape, class_probs=None):
-    """Region-proposal evaluation stage (reference scannet.py:145-155 / slic.py:93-99, with the
-    documented fix: the ensemble logits are soft-maxed over the class axis): bags -> ResNet bag
-    forward on the HIP path -> class per region -> painted label image (int64 ndarray)."""
+def predict_regions(model, iterator, metadata, label_shape, class_probs=None, rank=0, world=1):
+    """Region-proposal evaluation stage (reference scannet.py:145-155 / slic.py:93-99, with the documented fix: the
+    ensemble logits are soft-maxed over the class axis): bags -> ResNet bag forward on the HIP path -> class per region ->
+    painted label image (int64 ndarray).  With world > 1 (torch.distributed initialised) the bags are sharded over the ranks
+    by greedy cost balance, each rank runs its share, ONE all-gather of the (R, C) ensemble logits follows and every rank
+    paints the identical label image on its device (wsi_paint_regions)."""
+    from wsi_segmentation_pipeline_amd import bags as B
     class_probs = args.class_probs if class_probs is None else class_probs
     dev = _device_of(model)
     was_training = model.training
     model.eval()
-    pred_mask = np.zeros(label_shape, dtype=np.int64)
+    data = iterator.dataset
+    R = len(data)
+    shards = B.shard_bags(np.full(R, 16.0), world)
+    mine = iterator.shard(shards[rank]) if world > 1 else iterator
     with torch.no_grad():
-        for images, tile_ids in iterator:
-            _, ensemble = model(images.to(dev))
-            # (B,C) logits as a (C,B,1) "map": softmax over classes / threshold / argmax in one HIP kernel
-            as_map = ensemble.t().to(torch.float64).contiguous().view(ensemble.shape[1], -1, 1)
-            cls = E.softmax_threshold_argmax(as_map, class_probs, want_probs=False)[0].view(-1).cpu().numpy()
-            for tj, tile_id in enumerate(tile_ids.numpy()):
-                pred_mask[metadata[int(tile_id)]['foreground_indices']] = cls[tj]
+        parts = [model(images.to(dev))[1] for images, _ in mine]
+        num_classes = len(class_probs)
+        local = torch.cat(parts) if parts else torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
+        ens = B.gather_rows(local, shards, rank, world) if world > 1 else local
+        if R:
+            # (R,C) logits as a (C,R,1) "map": softmax over classes / threshold / argmax in one HIP kernel
+            as_map = ens.t().to(torch.float64).contiguous().view(ens.shape[1], -1, 1)
+            cls = E.softmax_threshold_argmax(as_map, class_probs, want_probs=False)[0].view(-1)
+            index_lists = [metadata[int(r['tile_id'])]['foreground_indices'] for r in data.datalist]
+            pred_mask = B.paint_regions(tuple(label_shape), index_lists, cls, dev).cpu().numpy()
+        else:
+            pred_mask = np.zeros(label_shape, dtype=np.int64)
     if was_training:
         model.train()
     return pred_mask

@@ -22,6 +22,8 @@ int wsi_stitch_add_dispatch(const float* logits, const int* txy, int T, int C, i
                             hipStream_t st);
 int wsi_stitch_add_dense_dispatch(const float* tiles, const int* txy, int T, int C, int ph, int pw, double* pred, int MH,
                                   int MW, hipStream_t st);
+int wsi_paint_dispatch(const long long* idx, const int* region_of, long long n, const uint8_t* cls, int* winner, long long* label,
+                       long long npix, hipStream_t st);
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
                          const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
 
@@ -488,6 +490,12 @@ int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const 
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream) {
     if (!pred || !class_thresh) return WSI_EINVAL;
     return wsi_softmax_dispatch(pred, c, hw, class_thresh, probs, classes, mask, heat_mode, heat, (hipStream_t)stream);
+}
+
+int wsi_paint_regions(const long long* pixel_idx, const int* region_of, long long n, const uint8_t* region_class, int* winner_scratch,
+                      long long* label, long long npix, void* stream) {
+    if (!region_class || !winner_scratch || !label || (n && (!pixel_idx || !region_of))) return WSI_EINVAL;
+    return wsi_paint_dispatch(pixel_idx, region_of, n, region_class, winner_scratch, label, npix, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ tumour-bed post-process

@@ -120,6 +120,76 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* x, const float
     }
 }
 
+// y = act(x W^T + b) as an fp32-input MFMA GEMM (v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chains, no operand
+// split needed) for the bag head `fc.0` = Linear(8192 -> 4096) + ReLU (/root/reference/resnets_shift.py:133-139,214-215).
+// r01 ran it on the wave-per-output VALU kernel above, which re-streams the 134 MB weight matrix once per 8 bags; here a
+// workgroup owns 64 bags x 128 outputs, every weight element is fetched once per 64 bags and meets them in the matrix
+// pipe.  Wave w: outputs [32w, 32w+32) x 64 bags = two 32x32 accumulators; K in steps of 32 through LDS (k-major tiles:
+// a lane's operand is one conflict-free ds_read_b32), next step's global loads in flight during the current step's MFMAs.
+__global__ __launch_bounds__(256) void linear_mfma_f32_kernel(const float* x, const float* w, const float* bias, float* y, int B,
+                                                              int K, int J, int relu) {
+    constexpr int BM = 64, BN = 128, KB = 32;
+    __shared__ float Xs[KB][BM];
+    __shared__ float Ws[KB][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // staging roles: X tile 64 rows x 32 k (8 k per thread), W tile 128 rows x 32 k (16 k per thread)
+    const int xr = tid >> 2, xk = (tid & 3) * 8;
+    const int wr = tid >> 1, wk = (tid & 1) * 16;
+    const float* xp = x + (size_t)min(m0 + xr, B - 1) * K + xk;
+    const float* wp = w + (size_t)(n0 + wr) * K + wk;
+    f32x4 xv[2], wv[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xv[q] = *(const f32x4*)(xp + k0 + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(wp + k0 + 4 * q);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Xs[xk + 4 * q + e][xr] = xv[q][e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ws[wk + 4 * q + e][wr] = wv[q][e];
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KB) {
+        __syncthreads();                                      // the previous step's reads are done
+        commit();
+        __syncthreads();
+        if (k0 + KB < K) fetch(k0 + KB);                      // in flight behind this step's 32 MFMAs
+#pragma unroll
+        for (int kk = 0; kk < KB / 2; ++kk) {
+            const float b = Ws[2 * kk + h][wave * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[2 * kk + h][mt * 32 + l31], b, acc[mt], 0, 0, 0);
+        }
+    }
+    const int j = n0 + wave * 32 + l31;
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < B) {
+                float v = acc[mt][r] + bj;
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)row * J + j] = v;
+            }
+        }
+}
+
 template <int PLANES>
 __global__ __launch_bounds__(256) void pf_pack_kernel(const float* in, void* out, PFGeom g) {
     const long long total = (long long)g.N * g.H * g.W * g.C;
@@ -214,6 +284,10 @@ int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, con
 int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
                         hipStream_t st) {
     if (K % 4 || B <= 0 || J <= 0) return WSI_EINVAL;
+    if (J % 128 == 0 && K % 32 == 0 && B >= 8 && (long long)J * K >= (1 << 20)) {     // the bag head fc.0 (4096 x 8192): matrix pipe
+        hipLaunchKernelGGL(linear_mfma_f32_kernel, dim3(J / 128, (B + 63) / 64), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
+        return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+    }
     hipLaunchKernelGGL(linear_kernel<8>, dim3((J + 3) / 4), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }

@@ -91,6 +91,23 @@ __global__ __launch_bounds__(256) void softmax_threshold_argmax_kernel(const dou
     }
 }
 
+// Region paint (/root/reference/scannet.py:154-155, slic.py:98-99: `pred_mask[metadata[tile_id]['foreground_indices']] = cls`
+// in region order, so where candidate regions overlap the LAST one wins).  Entry e = flat pixel index idx[e] of region
+// region_of[e] (regions numbered in paint order).  Pass 1 keeps, per pixel, the highest region number that covers it
+// (atomicMax: order-independent), pass 2 writes that region's class: deterministic whatever the overlap.
+__global__ __launch_bounds__(256) void paint_winner_kernel(const long long* idx, const int* region_of, long long n, int* winner, long long npix) {
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long p = idx[e];
+        if (p >= 0 && p < npix) atomicMax(&winner[p], region_of[e] + 1);
+    }
+}
+__global__ __launch_bounds__(256) void paint_write_kernel(const int* winner, const uint8_t* cls, long long npix, long long* label) {
+    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const int wn = winner[p];
+        if (wn > 0) label[p] = cls[wn - 1];
+    }
+}
+
 static int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -126,5 +143,14 @@ int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* 
     if (heat && ((heat_mode == 0 && C < 2) || (heat_mode == 1 && C < 4))) return WSI_EINVAL;
     hipLaunchKernelGGL(softmax_threshold_argmax_kernel, dim3(grid_for(HW)), dim3(256), 0, st, pred, C, HW, thresh, probs,
                        classes, mask, heat_mode, heat);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_paint_dispatch(const long long* idx, const int* region_of, long long n, const uint8_t* cls, int* winner, long long* label,
+                       long long npix, hipStream_t st) {
+    if (n < 0 || npix <= 0) return WSI_EINVAL;
+    if (hipMemsetAsync(winner, 0, (size_t)npix * sizeof(int), st) != hipSuccess) return WSI_EFAULT;
+    if (n) hipLaunchKernelGGL(paint_winner_kernel, dim3(grid_for(n)), dim3(256), 0, st, idx, region_of, n, winner, npix);
+    hipLaunchKernelGGL(paint_write_kernel, dim3(grid_for(npix)), dim3(256), 0, st, (const int*)winner, cls, npix, label);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }

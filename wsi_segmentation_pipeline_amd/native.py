@@ -73,6 +73,7 @@ SIGNATURES = {
     'wsi_stitch_add': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_stitch_add_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_softmax_threshold_argmax': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'wsi_paint_regions': (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp]),
     'wsi_resize_bilinear_f64': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_argmax_classes': (_i, [_vp, _i, _ll, _vp, _vp]),
     'wsi_morph_rect': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
