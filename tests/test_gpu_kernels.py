@@ -345,10 +345,11 @@ def test_pingpong_conv_equals_wide_kernel(dev, shape):
     assert ran > 0 or c < 128 or w > 33                        # (maps wider than 33: two slabs of this tile do not fit)
 
 
-@pytest.mark.parametrize('shape', [(8, 8192, 4096), (70, 8192, 4096), (200, 512, 128), (64, 64, 256), (65, 96, 128)])
+@pytest.mark.parametrize('shape', [(8, 8192, 4096), (70, 8192, 4096), (200, 512, 128), (64, 64, 256), (65, 96, 128), (2001, 4096, 4), (33, 128, 1),
+                                   (100, 512, 16), (40, 512, 9)])
 def test_linear_mfma_gemm(dev, shape):
-    """The bag head fc.0 = Linear(8192 -> 4096) + ReLU on the fp32-input MFMA GEMM (exact fp32 products) vs torch fp32 on the CPU;
-    ragged bag counts, with and without bias / ReLU."""
+    """The bag head fc.0 = Linear(8192 -> 4096) + ReLU on the fp32-input MFMA GEMM (exact fp32 products) and its second layer
+    Linear(4096 -> 4) on the wave-per-row kernel, vs torch fp32 on the CPU; ragged bag counts, with and without bias / ReLU."""
     import ctypes as C
     from wsi_segmentation_pipeline_amd import native
     lib = native.load()

@@ -75,6 +75,8 @@ def paint_regions(label_shape, index_lists, classes, device, prepared=None):
     idx_d, reg_d = prepared if prepared is not None else prepare_paint(label_shape, index_lists, dev)
     classes = classes.to(dev, torch.uint8).contiguous()
     label = torch.zeros(tuple(label_shape), dtype=torch.int64, device=dev)
+    if idx_d.numel() == 0:
+        return label
     winner = torch.empty(npix, dtype=torch.int32, device=dev)
     native.check(lib.wsi_paint_regions(_ptr(idx_d), _ptr(reg_d), idx_d.numel(), _ptr(classes), _ptr(winner), _ptr(label), npix, _stream()),
                  'wsi_paint_regions')

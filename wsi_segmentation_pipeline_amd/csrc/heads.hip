@@ -120,6 +120,42 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* x, const float
     }
 }
 
+// Few outputs, many rows (the bag head's second layer Linear(4096 -> 4) over thousands of bags, models.py Classifier /
+// Regressor tails): one wave per ROW, the J <= 16 weight rows (J x K floats, L2-resident) streamed by all waves.
+// linear_kernel above puts one wave on each OUTPUT and walks the rows serially: 22 ms for 2000 bags (r02 rocprof).
+template <int JMAX>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* x, const float* w, const float* bias, float* y, int B, int K,
+                                                          int J, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const f32x4* xr = (const f32x4*)(x + (size_t)b * K);
+    float acc[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) acc[j] = 0.f;
+    for (int k4 = lane; k4 < K / 4; k4 += 64) {
+        const f32x4 xv = xr[k4];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            if (j < J) {
+                const f32x4 wv = ((const f32x4*)(w + (size_t)j * K))[k4];
+                acc[j] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        if (j < J) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0) {
+                float v = s + (bias ? bias[j] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)b * J + j] = v;
+            }
+        }
+    }
+}
+
 // y = act(x W^T + b) as an fp32-input MFMA GEMM (v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chains, no operand
 // split needed) for the bag head `fc.0` = Linear(8192 -> 4096) + ReLU (/root/reference/resnets_shift.py:133-139,214-215).
 // r01 ran it on the wave-per-output VALU kernel above, which re-streams the 134 MB weight matrix once per 8 bags; here a
@@ -286,6 +322,11 @@ int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float
     if (K % 4 || B <= 0 || J <= 0) return WSI_EINVAL;
     if (J % 128 == 0 && K % 32 == 0 && B >= 8 && (long long)J * K >= (1 << 20)) {     // the bag head fc.0 (4096 x 8192): matrix pipe
         hipLaunchKernelGGL(linear_mfma_f32_kernel, dim3(J / 128, (B + 63) / 64), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
+        return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+    }
+    if (J <= 16 && B >= 32) {                                                          // few outputs, many rows: a wave per row
+        if (J <= 4) hipLaunchKernelGGL(linear_rows_kernel<4>, dim3((B + 3) / 4), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
+        else hipLaunchKernelGGL(linear_rows_kernel<16>, dim3((B + 3) / 4), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
         return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
     }
     hipLaunchKernelGGL(linear_kernel<8>, dim3((J + 3) / 4), dim3(256), 0, st, x, w, bias, y, B, K, J, relu);
