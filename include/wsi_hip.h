@@ -184,6 +184,25 @@ int wsi_stitch_add_dense(const float* tile_pred, const int* map_xy, int t, int c
                          int map_w, void* stream);
 int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream);
+/* ---- region-proposal generation (the step in front of the bag path; bit-exact against oracle/proposals_oracle.py) ----
+ *   wsi_find_nuclei_hsv        utils/preprocessing.py:94-98 (mode 'hsv'): skimage rgb2hsv saturation > mu_percent in float64 on
+ *                              packed u8 pixels (pixel_stride bytes apart, R G B first) -> 0/1 mask
+ *   wsi_connected_components   scannet.py:55 cv2.connectedComponentsWithStats((mask > 0)): 8-connected, int32 labels, 0 =
+ *                              background, 1.. in raster order of first pixels; count_out (device int) = number of components;
+ *                              scratch: wsi_connected_components_scratch_bytes.  Synchronises the stream (convergence flag).
+ *   wsi_kmeans_points          utils/regiontools.py:89 key points: Lloyd iterations from the caller's initial centres on integer
+ *                              (x, y) points, float64 distances, ties to the lower index, exact integer sums, empty clusters keep
+ *                              their centre, stops when no label changes (the reference's sklearn KMeans is RNG / version
+ *                              dependent: own deterministic spec); scratch: (3 k + 1) * 8 bytes.  Synchronises the stream. */
+int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, double mu_percent, uint8_t* mask_out, void* stream);
+size_t wsi_connected_components_scratch_bytes(int h, int w);
+int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream);
+int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream);
+/* guard of the float64 stitch (wsi_stitch_add / _dense use float64 atomics): out2 (device, 2 ints) = {smallest, largest} biased
+ * exponent of the nonzero finite values.  While (largest - smallest) + log2(addends per map pixel) <= 29 every float64 sum of
+ * these fp32 values is exact, so the accumulate is order-independent and bit-stable (like the reference's, whose DataLoader
+ * shuffles: utils/dataset.py:192) */
+int wsi_exponent_span(const float* values, long long n, int* out2, void* stream);
 /* region paint (scannet.py:154-155, slic.py:98-99): label[pixel_idx[e]] = region_class[region_of[e]] for every entry e, regions
  * numbered in paint order - where regions overlap the last one wins, as in the reference's loop; label is int64 (np.zeros of
  * the reference), untouched elsewhere; winner_scratch: npix ints */

@@ -389,3 +389,18 @@ def test_paint_regions_last_wins(dev):
     got = B.paint_regions(shape, lists, torch.from_numpy(cls).to(dev), dev)
     assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), ref)
     assert B.paint_regions(shape, [], torch.zeros(0, dtype=torch.uint8, device=dev), dev).sum().item() == 0
+
+
+def test_stitch_exponent_guard(dev):
+    """wsi_exponent_span + check_stitch_exact: the float64 atomics are exact (order-independent) only inside a bounded exponent
+    span; the guard measures it on the device and the driver refuses beyond it."""
+    from wsi_segmentation_pipeline_amd import engine as E
+    v = torch.tensor([0.0, 1.5, -3.0, 1e-3, float('inf'), float('nan'), 100.0], device=dev)
+    lo, hi = (int(t) for t in E.exponent_span(v).cpu())
+    assert (lo, hi) == (127 - 10, 127 + 6)                           # 1e-3 = 1.024 x 2^-10, 100 = 1.5625 x 2^6
+    E.check_stitch_exact(E.exponent_span(v), 16)                       # 16 + 4 bits: fine
+    wide = torch.tensor([1e-12, 1e3], device=dev)
+    with pytest.raises(RuntimeError):
+        E.check_stitch_exact(E.exponent_span(wide), 4)
+    assert [int(t) for t in E.exponent_span(torch.zeros(5, device=dev)).cpu()] == [255, 0]
+    E.check_stitch_exact(E.exponent_span(torch.zeros(5, device=dev)), 1000)

@@ -1,0 +1,112 @@
+"""Region-proposal kernels against oracle/proposals_oracle.py: bit-exact masks, labels, k-means labels / centres and the
+`metadata` of scannet_candidates (reference scannet.py:55-127, utils/regiontools.py:68-102, utils/preprocessing.py:94-98)."""
+import numpy as np
+import pytest
+import torch
+from scipy import ndimage
+
+from oracle import proposals_oracle as PO
+from oracle.wsi_oracle import find_nuclei_hsv
+from tests.test_proposals_oracle import blobs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def P():
+    from wsi_segmentation_pipeline_amd import proposals
+    return proposals
+
+
+def test_find_nuclei_hsv_exact(P):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (301, 517, 3), dtype=np.uint8)
+    img[:40] = 255
+    img[40:60] = 0
+    img[60:80, :, :] = rng.integers(0, 256, (20, 517, 1), dtype=np.uint8)         # grey: delta == 0
+    for mu in (0.1, 0.05, 0.5):
+        got = P.find_nuclei(torch.from_numpy(img).cuda(), mu).cpu().numpy()
+        assert np.array_equal(got, find_nuclei_hsv(img, mu))
+    rgba = np.concatenate((img, np.full(img.shape[:2] + (1,), 255, np.uint8)), -1)
+    assert np.array_equal(P.find_nuclei(torch.from_numpy(rgba).cuda()).cpu().numpy(), find_nuclei_hsv(img))
+    from utils import preprocessing
+    assert np.array_equal(preprocessing.find_nuclei(torch.from_numpy(img).cuda()).cpu().numpy(), preprocessing.find_nuclei(img))
+
+
+@pytest.mark.parametrize('seed,hw,p', [(0, (40, 57), 0.42), (1, (64, 64), 0.6), (2, (33, 130), 0.3), (3, (1, 50), 0.5), (4, (50, 1), 0.5)])
+def test_cc_exact_small(P, seed, hw, p):
+    mask = (np.random.default_rng(seed).random(hw) < p).astype(np.uint8)
+    lab, n = P.connected_components(torch.from_numpy(mask).cuda())
+    ref = PO.connected_components(mask)
+    assert n == ref.max()
+    assert np.array_equal(lab.cpu().numpy(), ref)
+
+
+def test_cc_edge_cases(P):
+    for m in (np.zeros((9, 11), np.uint8), np.ones((9, 11), np.uint8), np.eye(16, dtype=np.uint8),
+              (np.indices((31, 31)).sum(0) % 2).astype(np.uint8)):
+        lab, n = P.connected_components(torch.from_numpy(m).cuda())
+        assert np.array_equal(lab.cpu().numpy(), PO.connected_components(m))
+    # a long serpentine: one component whose union chain crosses the whole image
+    s = np.zeros((65, 200), np.uint8)
+    s[::2] = 1
+    s[1::4, -1] = 1
+    s[3::4, 0] = 1
+    lab, n = P.connected_components(torch.from_numpy(s).cuda())
+    assert n == 1 and np.array_equal(lab.cpu().numpy(), s.astype(np.int32))
+
+
+def test_cc_full_size_vs_scipy(P):
+    """A 2500 x 2500 thumbnail (cfg5 scale): same partition as scipy.ndimage.label and labels in raster order of first pixels."""
+    rng = np.random.default_rng(7)
+    coarse = rng.random((125, 125)) < 0.45
+    mask = np.kron(coarse, np.ones((20, 20), bool)) & (rng.random((2500, 2500)) < 0.97)
+    lab, n = P.connected_components(torch.from_numpy(mask.astype(np.uint8)).cuda())
+    lab = lab.cpu().numpy()
+    ref, nref = ndimage.label(mask, structure=np.ones((3, 3)))
+    assert n == nref
+    assert ((lab == 0) == (ref == 0)).all()
+    m = np.zeros(n + 1, np.int64)
+    m[lab.ravel()] = ref.ravel()                                                   # last writer: any pixel of the component
+    assert np.array_equal(m[lab], ref) and len(np.unique(m)) == n + 1
+    firsts = np.full(n + 1, lab.size, np.int64)
+    np.minimum.at(firsts, lab.ravel(), np.arange(lab.size))
+    assert (np.diff(firsts[1:]) > 0).all()
+
+
+@pytest.mark.parametrize('seed,n,k', [(0, 500, 3), (1, 4000, 7), (2, 64, 2), (3, 20000, 12)])
+def test_kmeans_exact(P, seed, n, k):
+    rng = np.random.default_rng(seed)
+    pts = rng.integers(0, 600, (n, 2))
+    pts = np.unique(pts, axis=0)
+    pts = pts[np.lexsort((pts[:, 0], pts[:, 1]))].astype(np.int32)
+    c, l = P.kmeans(torch.from_numpy(pts).cuda(), k)
+    rc, rl = PO.kmeans(pts, k)
+    assert np.array_equal(l.cpu().numpy(), rl)
+    assert np.array_equal(c.cpu().numpy(), rc)
+
+
+def test_key_points_exact(P):
+    gt = blobs(5)
+    n, cnt, out, fgi = P.get_key_points(torch.from_numpy(gt).cuda(), 4, 3)
+    rn, rcnt, rout, rfgi = PO.get_key_points(gt, 4, 3)
+    assert n == rn and np.array_equal(cnt, rcnt) and np.array_equal(out.cpu().numpy(), rout)
+    assert all(np.array_equal(a, b) for a, b in zip(fgi, rfgi))
+    assert P.get_key_points(torch.zeros((32, 32), dtype=torch.uint8).cuda(), 4, 3) == (None, None, None, None)
+    from utils import regiontools
+    n2, cnt2, out2, _ = regiontools.get_key_points(gt, 4, 3, 3)
+    assert n2 == rn and np.array_equal(cnt2, rcnt) and np.array_equal(out2, rout)
+
+
+@pytest.mark.parametrize('seed,hw,nb', [(5, (96, 128), 9), (6, (160, 200), 14), (8, (240, 240), 4)])
+def test_scannet_candidates_exact(P, seed, hw, nb):
+    gt = blobs(seed, hw, nb)
+    tissue = blobs(seed + 100, hw, 30)
+    got = P.scannet_candidates(torch.from_numpy(gt).cuda(), torch.from_numpy(tissue).cuda())
+    ref = PO.scannet_candidates(gt, tissue)
+    assert list(got) == list(ref)
+    for key in ref:
+        for f in ('cnt_xy', 'perim_xy'):
+            assert np.array_equal(got[key][f], ref[key][f]), (key, f)
+        assert all(np.array_equal(a, b) for a, b in zip(got[key]['foreground_indices'], ref[key]['foreground_indices']))
+        assert got[key]['tile_id'] == ref[key]['tile_id'] and got[key]['scan_level'] == 2

@@ -124,6 +124,9 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                     E.stitch_add_dense(pred, pred_src, torch.from_numpy(S.map_coords(xy, m)))
                 classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'seg', want_probs=False)
                 r = {'logits': None, 'pred': pred, 'classes': classes, 'heatmap': heat}
+            if r.get('exponent_span') is not None:             # the float64 stitch is exact (order-independent) inside this bound
+                over = (-(-ds.params.ph // ds.params.sh) + 1) * (-(-ds.params.pw // ds.params.sw) + 1)
+                E.check_stitch_exact(r['exponent_span'], over)
             heat = r['heatmap'].cpu().numpy()
             results[key] = {'heatmap': heat, 'classes': r['classes'].cpu().numpy(), 'logits': r['logits']}
             if save and rank == 0:

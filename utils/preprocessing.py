@@ -36,6 +36,9 @@ def find_nuclei(wsi, mu_percent=0.1, mode='hsv', fill_mask=False):
     rgb2hsv definition, which the reference calls)."""
     if mode != 'hsv' or fill_mask:
         raise NotImplementedError("only mode='hsv', fill_mask=False (the eval-path configuration) is provided")
+    if torch.is_tensor(wsi) and wsi.is_cuda:                       # device thumbnails stay on the device (wsi_find_nuclei_hsv)
+        from wsi_segmentation_pipeline_amd import proposals as P
+        return P.find_nuclei(wsi, mu_percent)
     rgb = np.asarray(wsi)[..., :3].astype(np.float64) / 255.0
     hi, lo = rgb.max(-1), rgb.min(-1)
     delta = hi - lo

@@ -1,7 +1,22 @@
 """Inference-side piece of the reference's ``utils.regiontools``: map_points
-(/root/reference/utils/regiontools.py:15-37).  Candidate generation (k-means key points) is
-ranked "next" in SURVEY.md 8f - region candidates are inputs to the hot path."""
+(/root/reference/utils/regiontools.py:15-37) and get_key_points (:68-102) on the device."""
 import numpy as np
+
+
+def get_key_points(image, us, min_clusters, max_clusters=None):
+    """Centre points of a region by k-means on its downsampled foreground (reference :68-102; `max_clusters` is accepted and
+    unused, as in the reference).  Runs on the HIP kernels of wsi_segmentation_pipeline_amd.proposals; `image` may be a GPU
+    tensor or an ndarray (uploaded).  Returns (n, (k,2) int centre points, cluster image ndarray, foreground_indices) or 4 x None.
+    The clustering is the deterministic Lloyd spec of oracle/proposals_oracle.py, not sklearn's RNG-dependent k-means++."""
+    import torch
+    from wsi_segmentation_pipeline_amd import proposals as P
+    if not torch.cuda.is_available():
+        raise RuntimeError('get_key_points runs on the HIP kernels (wsi_kmeans_points): no GPU available')
+    t = image if torch.is_tensor(image) else torch.from_numpy(np.ascontiguousarray(np.asarray(image) != 0).astype(np.uint8))
+    if not t.is_cuda:
+        t = t.to(torch.device('cuda', torch.cuda.current_device()))
+    n, cnt, out, fgi = P.get_key_points(t, us, min_clusters)
+    return n, cnt, (None if out is None else out.cpu().numpy().astype(np.uint16)), fgi
 
 
 def map_points(arr, params):

@@ -24,6 +24,11 @@ int wsi_stitch_add_dense_dispatch(const float* tiles, const int* txy, int T, int
                                   int MW, hipStream_t st);
 int wsi_paint_dispatch(const long long* idx, const int* region_of, long long n, const uint8_t* cls, int* winner, long long* label,
                        long long npix, hipStream_t st);
+int wsi_hsv_mask_dispatch(const uint8_t* rgb, long long npix, int stride, double thresh, uint8_t* mask, hipStream_t st);
+size_t wsi_cc_scratch_bytes(int H, int W);
+int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* count_out, void* scratch, hipStream_t st);
+int wsi_kmeans_dispatch(const int* pts, int n, double* centres, int k, int iters, int* labels, void* scratch, hipStream_t st);
+int wsi_exponent_span_dispatch(const float* v, long long n, int* out2, hipStream_t st);
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
                          const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
 
@@ -490,6 +495,26 @@ int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const 
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream) {
     if (!pred || !class_thresh) return WSI_EINVAL;
     return wsi_softmax_dispatch(pred, c, hw, class_thresh, probs, classes, mask, heat_mode, heat, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ region proposals
+int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, double mu_percent, uint8_t* mask_out, void* stream) {
+    if (!rgb || !mask_out) return WSI_EINVAL;
+    return wsi_hsv_mask_dispatch(rgb, npix, pixel_stride, mu_percent, mask_out, (hipStream_t)stream);
+}
+size_t wsi_connected_components_scratch_bytes(int h, int w) { return (h <= 0 || w <= 0) ? 0 : wsi_cc_scratch_bytes(h, w); }
+int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream) {
+    if (!mask || !labels_out || !scratch) return WSI_EINVAL;
+    return wsi_cc_dispatch(mask, h, w, labels_out, count_out, scratch, (hipStream_t)stream);
+}
+int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream) {
+    if (!points_xy || !centres_xy || !labels_out || !scratch) return WSI_EINVAL;
+    return wsi_kmeans_dispatch(points_xy, n, centres_xy, k, max_iters, labels_out, scratch, (hipStream_t)stream);
+}
+
+int wsi_exponent_span(const float* values, long long n, int* out2, void* stream) {
+    if (!values || !out2) return WSI_EINVAL;
+    return wsi_exponent_span_dispatch(values, n, out2, (hipStream_t)stream);
 }
 
 int wsi_paint_regions(const long long* pixel_idx, const int* region_of, long long n, const uint8_t* region_class, int* winner_scratch,

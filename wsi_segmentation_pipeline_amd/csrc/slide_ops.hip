@@ -62,6 +62,21 @@ __global__ __launch_bounds__(256) void stitch_add_dense_kernel(const float* tile
     }
 }
 
+// Guard of the float64 stitch: sums of fp32 addends are EXACT in float64 (hence independent of the atomics' order, and of
+// the reference's shuffled DataLoader order) while  exponent span of the addends + log2(addends per pixel) <= 29 bits.
+// out2[0] = smallest, out2[1] = largest biased exponent among the nonzero finite values (255 / 0 when there are none).
+__global__ __launch_bounds__(256) void exponent_span_kernel(const float* v, long long n, int* out2) {
+    int lo = 255, hi = 0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned e = (__float_as_uint(v[i]) >> 23) & 255u, m = __float_as_uint(v[i]) & 0x7fffffu;
+        if (e == 255u || (e == 0u && m == 0u)) continue;               // inf / nan / zero
+        lo = min(lo, (int)e); hi = max(hi, (int)e);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out2[0], lo); atomicMax(&out2[1], hi); }
+}
+
 #define WSI_MAX_CLASSES 16
 __global__ __launch_bounds__(256) void softmax_threshold_argmax_kernel(const double* pred, int C, long long HW,
                                                                        const double* thresh, double* probs,
@@ -152,5 +167,13 @@ int wsi_paint_dispatch(const long long* idx, const int* region_of, long long n, 
     if (hipMemsetAsync(winner, 0, (size_t)npix * sizeof(int), st) != hipSuccess) return WSI_EFAULT;
     if (n) hipLaunchKernelGGL(paint_winner_kernel, dim3(grid_for(n)), dim3(256), 0, st, idx, region_of, n, winner, npix);
     hipLaunchKernelGGL(paint_write_kernel, dim3(grid_for(npix)), dim3(256), 0, st, (const int*)winner, cls, npix, label);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+int wsi_exponent_span_dispatch(const float* v, long long n, int* out2, hipStream_t st) {
+    if (n <= 0) return WSI_EINVAL;
+    const int init[2] = {255, 0};
+    if (hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return WSI_EFAULT;
+    hipLaunchKernelGGL(exponent_span_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, st, v, n, out2);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }

@@ -428,6 +428,27 @@ def stitch_add(pred, tile_logits, map_xy, dy, dx):
     return pred
 
 
+def exponent_span(values):
+    """Device tensor of 2 ints: {smallest, largest} biased fp32 exponent of the nonzero finite values (stitch guard)."""
+    lib = native.load()
+    _require_gpu(values, 'values')
+    v = values.to(torch.float32).contiguous()
+    out = torch.empty(2, dtype=torch.int32, device=v.device)
+    if v.numel() == 0:
+        out[0], out[1] = 255, 0
+        return out
+    native.check(lib.wsi_exponent_span(_ptr(v), v.numel(), _ptr(out), _stream()), 'wsi_exponent_span')
+    return out
+
+
+def check_stitch_exact(span, addends_per_pixel):
+    """Raise if float64 sums of the guarded fp32 values could be inexact (order-dependent): see wsi_exponent_span."""
+    lo, hi = (int(v) for v in span.cpu())
+    if hi >= lo and (hi - lo) + int(np.ceil(np.log2(max(1, addends_per_pixel)))) > 29:
+        raise RuntimeError('stitch: the per-tile values span 2^%d with up to %d addends per pixel: float64 sums are no longer exact, '
+                           'so the accumulated map would depend on the order of the tiles' % (hi - lo, addends_per_pixel))
+
+
 def stitch_add_dense(pred, tile_pred, map_xy):
     """pred (C,MH,MW) float64 GPU += tile_pred (T,C,ph,pw) fp32 blocks at map_xy (T,2) int32 (clipped at the border)."""
     lib = native.load()

@@ -73,6 +73,11 @@ SIGNATURES = {
     'wsi_stitch_add': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_stitch_add_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_softmax_threshold_argmax': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'wsi_find_nuclei_hsv': (_i, [_vp, _ll, _i, C.c_double, _vp, _vp]),
+    'wsi_connected_components_scratch_bytes': (_sz, [_i, _i]),
+    'wsi_connected_components': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    'wsi_kmeans_points': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'wsi_exponent_span': (_i, [_vp, _ll, _vp, _vp]),
     'wsi_paint_regions': (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp]),
     'wsi_resize_bilinear_f64': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_argmax_classes': (_i, [_vp, _i, _ll, _vp, _vp]),

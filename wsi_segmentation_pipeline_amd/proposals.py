@@ -1,0 +1,130 @@
+"""Region-proposal generation on the device: foreground mask, connected components, key points and
+perimeter points per candidate region - the `metadata` the bag path consumes (reference scannet.py:55-127,
+utils/regiontools.py:68-102, utils/preprocessing.py:74-110).  Spec: oracle/proposals_oracle.py (parity unpinned where the
+reference calls cv2 / PIL / sklearn / mahotas; see its header).  The per-pixel work (mask, labelling, k-means assignment,
+perimeter) runs in HIP kernels; the host only walks the list of regions."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import native
+from . import postprocess as PP
+from .engine import _ptr, _require_gpu, _stream
+
+HR_NUM_PERIM_SAMPLES = 8
+KMEANS_ITERS = 25
+
+
+def find_nuclei(rgb_u8, mu_percent=0.1):
+    """(H,W,3|4) uint8 GPU image -> uint8 0/1 mask of HSV saturation > mu_percent (reference find_nuclei, mode 'hsv')."""
+    lib = native.load()
+    _require_gpu(rgb_u8, 'thumbnail')
+    if rgb_u8.dtype != torch.uint8 or rgb_u8.dim() != 3 or rgb_u8.shape[2] < 3:
+        raise ValueError('expected an (H,W,3) uint8 image')
+    img = rgb_u8.contiguous()
+    h, w, c = img.shape
+    mask = torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    native.check(lib.wsi_find_nuclei_hsv(_ptr(img), h * w, c, float(mu_percent), _ptr(mask), _stream()), 'wsi_find_nuclei_hsv')
+    return mask
+
+
+def connected_components(mask):
+    """uint8 / bool (H,W) GPU mask -> (int32 labels, count): 8-connected, numbered in raster order of first pixels."""
+    lib = native.load()
+    _require_gpu(mask, 'mask')
+    m = (mask != 0).to(torch.uint8).contiguous()
+    h, w = m.shape
+    labels = torch.empty((h, w), dtype=torch.int32, device=m.device)
+    count = torch.zeros(1, dtype=torch.int32, device=m.device)
+    scratch = torch.empty(lib.wsi_connected_components_scratch_bytes(h, w), dtype=torch.uint8, device=m.device)
+    native.check(lib.wsi_connected_components(_ptr(m), h, w, _ptr(labels), _ptr(count), _ptr(scratch), _stream()), 'wsi_connected_components')
+    return labels, int(count.item())
+
+
+def resize_nearest_idx(n_src, n_dst, device):
+    return torch.clamp(((torch.arange(n_dst, device=device, dtype=torch.float64) + 0.5) * n_src / n_dst).to(torch.int64), max=n_src - 1)
+
+
+def _resize_nearest(img, out_hw):
+    ys = resize_nearest_idx(img.shape[0], out_hw[0], img.device)
+    xs = resize_nearest_idx(img.shape[1], out_hw[1], img.device)
+    return img[ys][:, xs]
+
+
+def kmeans(points_xy, k, iters=KMEANS_ITERS):
+    """(N,2) int32 GPU points (raster order) -> (centres (k,2) float64, labels (N,) int32) by the deterministic Lloyd spec."""
+    lib = native.load()
+    pts = points_xy.to(torch.int32).contiguous()
+    n = pts.shape[0]
+    init = torch.tensor([(2 * j + 1) * n // (2 * k) for j in range(k)], device=pts.device)
+    centres = pts[init].to(torch.float64).contiguous()
+    labels = torch.empty(n, dtype=torch.int32, device=pts.device)
+    scratch = torch.empty((3 * k + 1) * 8, dtype=torch.uint8, device=pts.device)
+    native.check(lib.wsi_kmeans_points(_ptr(pts), n, _ptr(centres), k, iters, _ptr(labels), _ptr(scratch), _stream()), 'wsi_kmeans_points')
+    return centres, labels
+
+
+def get_key_points(patch, us, min_clusters):
+    """reference utils/regiontools.py:68-102 on a bool/uint8 (H,W) GPU patch -> (n, cnt_pts (k,2) int64 ndarray, cluster image
+    (H,W) uint16 GPU tensor, foreground_indices (tuple of ndarrays)) or 4 x None."""
+    img = (patch != 0).to(torch.uint8)
+    y, x = img.shape
+    small = _resize_nearest(img, (y // us, x // us))
+    fg = torch.nonzero(small)                                   # raster order, (row, col)
+    k = int(min_clusters)
+    if k <= 1 or fg.shape[0] <= 3 * k:
+        return None, None, None, None
+    coords = fg.flip(1).to(torch.int32).contiguous()            # (x, y)
+    centres, labels = kmeans(coords, k)
+    cnt_pts = (us * centres.cpu().numpy()).astype(np.int64)
+    out = torch.zeros(small.shape, dtype=torch.int32, device=img.device)
+    out[fg[:, 0], fg[:, 1]] = labels + 1
+    out = _resize_nearest(out, (y, x))
+    nz = torch.nonzero(out)
+    return k, cnt_pts, out, (nz[:, 0].cpu().numpy(), nz[:, 1].cpu().numpy())
+
+
+def _perim_points(patch):
+    per = PP.bwperim(patch.to(torch.uint8))
+    pc = torch.nonzero(per).flip(1).cpu().numpy()               # (x, y) pairs in np.where order
+    skip = max(2, pc.shape[0] // HR_NUM_PERIM_SAMPLES)
+    return pc[::skip, :]
+
+
+def scannet_candidates(gt_mask, wsi_mask, us_kmeans=4):
+    """reference scannet.py:55-127 on the device: `metadata` {patch_id: {cnt_xy, perim_xy, scan_level, foreground_indices, tile_id}}
+    from the ground-truth thumbnail and the tissue mask (both (H,W) GPU tensors)."""
+    _require_gpu(gt_mask, 'ground-truth thumbnail')
+    labels, _ = connected_components(gt_mask > 0)
+    nlab = int(labels.max().item())
+    size = labels.numel()
+    wsi_mask = wsi_mask.to(labels.device)
+    metadata, patch_id = {}, 0
+    for tile_id in range(nlab):                                 # the reference's range: background label 0 first, last label never
+        patch = labels == tile_id
+        area = int(patch.sum().item())
+        if area == 0:
+            continue
+        k = 2 + int(area / (0.01 * size))
+        n, cnt, out_image, fgi = get_key_points(patch, us_kmeans, k)
+        rows = torch.nonzero(patch.any(1)).view(-1)
+        cols = torch.nonzero(patch.any(0)).view(-1)
+        h = 1 + int(rows[-1] - rows[0])
+        w = 1 + int(cols[-1] - cols[0])
+        if n is not None and (w * h) / size <= 0.05:
+            metadata[patch_id] = {'cnt_xy': cnt, 'perim_xy': _perim_points(patch), 'scan_level': 2, 'foreground_indices': fgi, 'tile_id': patch_id}
+            patch_id += 1
+        elif n is not None:
+            for r_id in range(1, n + 1):
+                sub = out_image == r_id
+                sn, scnt, _, sfgi = get_key_points(sub, us_kmeans, k)
+                if sn is None:
+                    continue
+                if tile_id == 0:
+                    inside = int((wsi_mask[torch.from_numpy(sfgi[0]).to(labels.device), torch.from_numpy(sfgi[1]).to(labels.device)] != 0).sum().item())
+                    if inside / sfgi[0].shape[0] < 0.5:
+                        continue
+                metadata[patch_id] = {'cnt_xy': scnt, 'perim_xy': _perim_points(sub), 'scan_level': 2, 'foreground_indices': sfgi, 'tile_id': patch_id}
+                patch_id += 1
+    return metadata

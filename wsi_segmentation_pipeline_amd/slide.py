@@ -270,8 +270,10 @@ def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classe
         logits = torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
     logits = gather_tile_logits(logits, T, rank, world)
     pred = torch.zeros((num_classes, map_hw[0], map_hw[1]), dtype=torch.float64, device=dev)
+    span = None
     if T:
         mxy = _upload(map_coords(tile_xy, m), torch.int32, dev)
         E.stitch_add(pred, logits, mxy, int(m * ph), int(m * pw))
+        span = E.exponent_span(logits)                    # guard of the float64 atomics (checked by the caller: no sync here)
     classes, probs, heat = E.softmax_threshold_argmax(pred, class_probs, mask_dev, 'cls', want_probs)
-    return {'logits': logits, 'pred': pred, 'classes': classes, 'probs': probs, 'heatmap': heat}
+    return {'logits': logits, 'pred': pred, 'classes': classes, 'probs': probs, 'heatmap': heat, 'exponent_span': span}
