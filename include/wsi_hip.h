@@ -184,6 +184,33 @@ int wsi_stitch_add_dense(const float* tile_pred, const int* map_xy, int t, int c
                          int map_w, void* stream);
 int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const double* class_thresh, double* probs,
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream);
+/* ---- slide ingestion in front of the tile producer (utils/dataset.py:171-185: read_region(...).convert('RGB') [+ image.resize]) ----
+ *   wsi_ring_*        `slots` pinned-host buffers of slot_bytes (multiple of 4) + device staging + a copy stream of the ring's own.
+ *                     Producer protocol per band: wsi_ring_wait_slot (blocks until that slot's previous copy has landed) ->
+ *                     decode into wsi_ring_host_slot (any thread) -> wsi_ring_submit (one thread at a time): async H2D + unpack of
+ *                     `rows` x `width` pixels of `channels` (3, or 4 with the alpha byte dropped like PIL convert('RGB')) bytes,
+ *                     row pitch src_pitch, into level_rows (device pointer to the first destination row, pitch level_pitch).
+ *                     wsi_ring_fence makes compute_stream wait for everything submitted so far (no host block); wsi_ring_drain
+ *                     blocks the host.  Nothing here touches the compute stream otherwise: decode, copies and the trunk overlap.
+ *   wsi_resample_*    the scan_resize != 1 branch (utils/dataset.py:180-181 `image.resize((tile_w, tile_h))`, Pillow's default
+ *                     BICUBIC): n tiles of (in_h, in_w) read from the u8 slide at tile_xy (out-of-slide pixels 0) -> out
+ *                     (n, out_h, out_w, 3) u8, bit-exact with Pillow (22-bit fixed-point taps, horizontal then vertical pass, u8
+ *                     between); scratch: wsi_resample_scratch_bytes(plan, n).  A plan holds the tap tables on the current device
+ *                     (creation synchronises; reuse it). */
+typedef struct wsi_ring wsi_ring;
+typedef struct wsi_resample_plan wsi_resample_plan;
+int wsi_ring_create(wsi_ring** out, int slots, size_t slot_bytes);
+void* wsi_ring_host_slot(wsi_ring* ring, int slot);
+int wsi_ring_wait_slot(wsi_ring* ring, int slot);
+int wsi_ring_submit(wsi_ring* ring, int slot, int rows, int width, int channels, long long src_pitch, uint8_t* level_rows, long long level_pitch);
+int wsi_ring_fence(wsi_ring* ring, void* compute_stream);
+int wsi_ring_drain(wsi_ring* ring);
+void wsi_ring_destroy(wsi_ring* ring);
+int wsi_resample_plan_create(wsi_resample_plan** out, int in_h, int in_w, int out_h, int out_w);
+void wsi_resample_plan_destroy(wsi_resample_plan* plan);
+size_t wsi_resample_scratch_bytes(const wsi_resample_plan* plan, int n);
+int wsi_resample_tiles(const wsi_resample_plan* plan, const uint8_t* slide, long long pitch, int sh, int sw, const int* tile_xy, int n,
+                       uint8_t* out, void* scratch, void* stream);
 /* ---- region-proposal generation (the step in front of the bag path; bit-exact against oracle/proposals_oracle.py) ----
  *   wsi_find_nuclei_hsv        utils/preprocessing.py:94-98 (mode 'hsv'): skimage rgb2hsv saturation > mu_percent in float64 on
  *                              packed u8 pixels (pixel_stride bytes apart, R G B first) -> 0/1 mask

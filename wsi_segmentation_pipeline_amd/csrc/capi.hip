@@ -94,6 +94,22 @@ static inline uint16_t f16_bits(float x) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ingest.hip (C++ linkage)
+struct wsi_ring;
+struct wsi_resample_plan;
+int wsi_ring_create_impl(wsi_ring** out, int slots, size_t slot_bytes);
+void* wsi_ring_host_slot_impl(wsi_ring* r, int slot);
+int wsi_ring_wait_slot_impl(wsi_ring* r, int slot);
+int wsi_ring_submit_impl(wsi_ring* r, int slot, int rows, int width, int channels, long long src_pitch, uint8_t* dst, long long dst_pitch);
+int wsi_ring_fence_impl(wsi_ring* r, hipStream_t compute);
+int wsi_ring_drain_impl(wsi_ring* r);
+void wsi_ring_destroy_impl(wsi_ring* r);
+int wsi_resample_plan_create_impl(wsi_resample_plan** out, int in_h, int in_w, int out_h, int out_w);
+void wsi_resample_plan_destroy_impl(wsi_resample_plan* p);
+size_t wsi_resample_scratch_bytes_impl(const wsi_resample_plan* p, int n);
+int wsi_resample_tiles_impl(const wsi_resample_plan* p, const uint8_t* slide, long long pitch, int SH, int SW, const int* origins, int N,
+                            uint8_t* out, void* scratch, hipStream_t st);
+
 extern "C" {
 
 int wsi_hip_abi_version(void) { return WSI_HIP_ABI_VERSION; }
@@ -495,6 +511,26 @@ int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const 
                                  uint8_t* classes, const uint8_t* mask, int heat_mode, uint8_t* heat, void* stream) {
     if (!pred || !class_thresh) return WSI_EINVAL;
     return wsi_softmax_dispatch(pred, c, hw, class_thresh, probs, classes, mask, heat_mode, heat, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ ingestion ring + input resize
+int wsi_ring_create(wsi_ring** out, int slots, size_t slot_bytes) { return wsi_ring_create_impl(out, slots, slot_bytes); }
+void* wsi_ring_host_slot(wsi_ring* r, int slot) { return wsi_ring_host_slot_impl(r, slot); }
+int wsi_ring_wait_slot(wsi_ring* r, int slot) { return wsi_ring_wait_slot_impl(r, slot); }
+int wsi_ring_submit(wsi_ring* r, int slot, int rows, int width, int channels, long long src_pitch, uint8_t* level_rows, long long level_pitch) {
+    return wsi_ring_submit_impl(r, slot, rows, width, channels, src_pitch, level_rows, level_pitch);
+}
+int wsi_ring_fence(wsi_ring* r, void* compute_stream) { return wsi_ring_fence_impl(r, (hipStream_t)compute_stream); }
+int wsi_ring_drain(wsi_ring* r) { return wsi_ring_drain_impl(r); }
+void wsi_ring_destroy(wsi_ring* r) { wsi_ring_destroy_impl(r); }
+int wsi_resample_plan_create(wsi_resample_plan** out, int in_h, int in_w, int out_h, int out_w) {
+    return wsi_resample_plan_create_impl(out, in_h, in_w, out_h, out_w);
+}
+void wsi_resample_plan_destroy(wsi_resample_plan* p) { wsi_resample_plan_destroy_impl(p); }
+size_t wsi_resample_scratch_bytes(const wsi_resample_plan* p, int n) { return wsi_resample_scratch_bytes_impl(p, n); }
+int wsi_resample_tiles(const wsi_resample_plan* p, const uint8_t* slide, long long pitch, int sh, int sw, const int* tile_xy, int n,
+                       uint8_t* out, void* scratch, void* stream) {
+    return wsi_resample_tiles_impl(p, slide, pitch, sh, sw, tile_xy, n, out, scratch, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ region proposals

@@ -73,6 +73,17 @@ SIGNATURES = {
     'wsi_stitch_add': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_stitch_add_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'wsi_softmax_threshold_argmax': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'wsi_ring_create': (_i, [_vp, _i, _sz]),
+    'wsi_ring_host_slot': (_vp, [_vp, _i]),
+    'wsi_ring_wait_slot': (_i, [_vp, _i]),
+    'wsi_ring_submit': (_i, [_vp, _i, _i, _i, _i, _ll, _vp, _ll]),
+    'wsi_ring_fence': (_i, [_vp, _vp]),
+    'wsi_ring_drain': (_i, [_vp]),
+    'wsi_ring_destroy': (None, [_vp]),
+    'wsi_resample_plan_create': (_i, [_vp, _i, _i, _i, _i]),
+    'wsi_resample_plan_destroy': (None, [_vp]),
+    'wsi_resample_scratch_bytes': (_sz, [_vp, _i]),
+    'wsi_resample_tiles': (_i, [_vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'wsi_find_nuclei_hsv': (_i, [_vp, _ll, _i, C.c_double, _vp, _vp]),
     'wsi_connected_components_scratch_bytes': (_sz, [_i, _i]),
     'wsi_connected_components': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),

@@ -50,7 +50,13 @@ class ArraySlide:
         t = self._dev.get(key)
         if t is None:
             l = self.levels[level]
-            t = l.to(device) if isinstance(l, torch.Tensor) else torch.from_numpy(l).to(device)
+            if isinstance(l, torch.Tensor):
+                t = l.to(device)
+            elif l.nbytes >= (32 << 20):                       # host arrays / memmaps: pinned ring, copies overlap the band reads
+                from . import ingest
+                t = ingest.level_from_array(l, device)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(l)).to(device)
             self._dev[key] = t.contiguous()
         return self._dev[key]
 
