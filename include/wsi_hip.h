@@ -225,6 +225,15 @@ int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, do
 size_t wsi_connected_components_scratch_bytes(int h, int w);
 int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream);
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream);
+/* tile list of the sliding-window path on the device (utils/dataset.py:143-166): candidates in the reference's order (interior
+ * raster from (1,1) with strides (sw, sh), then the right-edge column x = iw-1-pw, then the bottom-edge row y = ih-1-ph), kept iff
+ * the mask window mask[int(y*m) : +int(ph*m), int(x*m) : +int(pw*m)] (clipped like a numpy slice; mask == NULL keeps all) has a
+ * nonzero fraction >= thresh.  tile_xy_out: room for wsi_tile_grid_candidates pairs, filled compacted in order; count_out: device int;
+ * scratch: wsi_tile_grid_scratch_bytes(candidates). */
+long long wsi_tile_grid_candidates(int iw, int ih, int ph, int pw, int sh, int sw);
+size_t wsi_tile_grid_scratch_bytes(long long candidates);
+int wsi_tile_grid(int iw, int ih, int ph, int pw, int sh, int sw, const uint8_t* mask, int mask_h, int mask_w, double m, double thresh,
+                  int* tile_xy_out, int* count_out, void* scratch, void* stream);
 /* guard of the float64 stitch (wsi_stitch_add / _dense use float64 atomics): out2 (device, 2 ints) = {smallest, largest} biased
  * exponent of the nonzero finite values.  While (largest - smallest) + log2(addends per map pixel) <= 29 every float64 sum of
  * these fp32 values is exact, so the accumulate is order-independent and bit-stable (like the reference's, whose DataLoader

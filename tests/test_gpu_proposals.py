@@ -110,3 +110,21 @@ def test_scannet_candidates_exact(P, seed, hw, nb):
             assert np.array_equal(got[key][f], ref[key][f]), (key, f)
         assert all(np.array_equal(a, b) for a, b in zip(got[key]['foreground_indices'], ref[key]['foreground_indices']))
         assert got[key]['tile_id'] == ref[key]['tile_id'] and got[key]['scan_level'] == 2
+
+
+@pytest.mark.parametrize('iw,ih,ph,pw,sh,sw,m,seed', [(904, 1112, 256, 256, 64, 64, 1.0, 0), (2000, 1500, 256, 256, 256, 256, 0.25, 1),
+                                                       (700, 650, 128, 128, 96, 96, 0.0625, 2), (300, 300, 256, 256, 32, 32, 1.0, 3),
+                                                       (250, 250, 256, 256, 32, 32, 1.0, 4), (5000, 4000, 256, 256, 32, 32, 0.25, 5)])
+def test_tile_grid_device_equals_oracle(iw, ih, ph, pw, sh, sw, m, seed):
+    """wsi_tile_grid == the reference loops (oracle.wsi_oracle.tile_grid) tile for tile, in order."""
+    from oracle import wsi_oracle as WO
+    from wsi_segmentation_pipeline_amd import slide as S
+    rng = np.random.default_rng(seed)
+    mh, mw = max(1, int(ih * m)), max(1, int(iw * m))
+    coarse = rng.random((mh // 8 + 1, mw // 8 + 1)) < 0.5
+    mask = (np.kron(coarse, np.ones((8, 8), bool))[:mh, :mw] & (rng.random((mh, mw)) < 0.12)).astype(np.uint8)
+    for mk in (None, mask):
+        got = S.tile_grid_device(iw, ih, ph, pw, sh, sw, None if mk is None else torch.from_numpy(mk).cuda(), m, device='cuda:0').cpu().numpy()
+        want = np.array(WO.tile_grid(iw, ih, ph, pw, sh, sw, mk, m), np.int32).reshape(-1, 2)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        assert np.array_equal(got, S.tile_grid(iw, ih, ph, pw, sh, sw, mk, m))

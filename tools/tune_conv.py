@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsi_segmentation_pipeline_amd import engine as E, native  # noqa: E402
 
 SHAPES = [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]      # (C, H, W) for 256x256 patches
-NCFG = 79
+NCFG = 80
 
 
 def main():
@@ -29,12 +29,13 @@ def main():
     ap.add_argument('--zero', action='store_true', help='all-zero activations (clock / power test)')
     ap.add_argument('--wcopies', type=int, default=1, help='study: replicate the packed weights N times (<= 16), workgroups spread over the copies')
     ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
+    ap.add_argument('--shapes', type=str, default='', help='comma list of indices into SHAPES')
     args = ap.parse_args()
     lib = native.load()
     dev = torch.device('cuda:0')
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(0)
-    for (c, h, w) in SHAPES:
+    for (c, h, w) in ([SHAPES[int(i)] for i in args.shapes.split(',')] if args.shapes else SHAPES):
         h, w = h // args.scale, w // args.scale
         n = args.n
         x = torch.randn(n, c, h, w, generator=g).abs_()

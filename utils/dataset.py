@@ -85,8 +85,12 @@ class Dataset_wsi:
         ref_level = min(2, len(self.scan.level_downsamples) - 1)
         m = self.scan.level_downsamples[args.scan_level] / self.scan.level_downsamples[ref_level]
         self.m = m
-        grid = S.tile_grid(self.params.iw, self.params.ih, self.params.ph, self.params.pw, self.params.sh, self.params.sw,
-                           mask, m)
+        if torch.cuda.is_available():       # enumeration + foreground filter + compaction on the device (wsi_tile_grid)
+            grid = S.tile_grid_device(self.params.iw, self.params.ih, self.params.ph, self.params.pw, self.params.sh, self.params.sw,
+                                      mask, m).cpu().numpy()
+        else:                               # host tooling without a GPU (tile lists only; nothing can be inferred there)
+            grid = S.tile_grid(self.params.iw, self.params.ih, self.params.ph, self.params.pw, self.params.sh, self.params.sw,
+                               mask, m)
         self.tile_xy = grid
         self.datalist = [(int(x), int(y)) for x, y in grid]
 

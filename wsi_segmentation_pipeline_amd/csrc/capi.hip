@@ -94,6 +94,10 @@ static inline uint16_t f16_bits(float x) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+long long wsi_tile_grid_candidates_impl(int iw, int ih, int ph, int pw, int sh, int sw);
+size_t wsi_tile_grid_scratch_bytes_impl(long long n);
+int wsi_tile_grid_dispatch(int iw, int ih, int ph, int pw, int sh, int sw, const uint8_t* mask, int MH, int MW, double m, double thresh,
+                           int* out_xy, int* count_out, void* scratch, hipStream_t st);
 // ingest.hip (C++ linkage)
 struct wsi_ring;
 struct wsi_resample_plan;
@@ -546,6 +550,14 @@ int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out,
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream) {
     if (!points_xy || !centres_xy || !labels_out || !scratch) return WSI_EINVAL;
     return wsi_kmeans_dispatch(points_xy, n, centres_xy, k, max_iters, labels_out, scratch, (hipStream_t)stream);
+}
+
+long long wsi_tile_grid_candidates(int iw, int ih, int ph, int pw, int sh, int sw) { return wsi_tile_grid_candidates_impl(iw, ih, ph, pw, sh, sw); }
+size_t wsi_tile_grid_scratch_bytes(long long candidates) { return candidates < 0 ? 0 : wsi_tile_grid_scratch_bytes_impl(candidates); }
+int wsi_tile_grid(int iw, int ih, int ph, int pw, int sh, int sw, const uint8_t* mask, int mask_h, int mask_w, double m, double thresh,
+                  int* tile_xy_out, int* count_out, void* scratch, void* stream) {
+    if (!tile_xy_out || !count_out || !scratch) return WSI_EINVAL;
+    return wsi_tile_grid_dispatch(iw, ih, ph, pw, sh, sw, mask, mask_h, mask_w, m, thresh, tile_xy_out, count_out, scratch, (hipStream_t)stream);
 }
 
 int wsi_exponent_span(const float* values, long long n, int* out2, void* stream) {

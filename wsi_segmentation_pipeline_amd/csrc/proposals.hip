@@ -131,6 +131,52 @@ __global__ void kmeans_update_kernel(double* centres, int k, const unsigned long
     }
 }
 
+// ------------------------------------------------------------------------------------------ tile grid (sliding-window path)
+// /root/reference/utils/dataset.py:143-166: candidates in the reference's order (interior raster, right-edge column, bottom-edge
+// row, no corner), kept iff the level-2 mask window mask[yp:yp+dy, xp:xp+dx] (numpy slice clipping) is >= thresh nonzero.
+struct TileGridArgs {
+    int iw, ih, ph, pw, sh, sw, ny, nx, dx, dy, MH, MW;
+    double m, thresh;
+    const uint8_t* mask;
+};
+static __device__ inline void tile_at(const TileGridArgs& g, long long i, int& x, int& y) {
+    const long long interior = (long long)g.ny * g.nx;
+    if (i < interior) { y = 1 + (int)(i / g.nx) * g.sh; x = 1 + (int)(i % g.nx) * g.sw; }
+    else if (i < interior + g.ny) { x = g.iw - 1 - g.pw; y = 1 + (int)(i - interior) * g.sh; }
+    else { y = g.ih - 1 - g.ph; x = 1 + (int)(i - interior - g.ny) * g.sw; }
+}
+__global__ __launch_bounds__(256) void tile_keep_kernel(TileGridArgs g, long long n, int* flags) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        int keep = 1;
+        if (g.mask) {
+            int x, y;
+            tile_at(g, i, x, y);
+            const long long yp = (long long)((double)y * g.m), xp = (long long)((double)x * g.m);      // int(ypos * m)
+            const long long y1 = min(yp + g.dy, (long long)g.MH), x1 = min(xp + g.dx, (long long)g.MW);
+            const long long rows = y1 - yp, cols = x1 - xp;
+            keep = 0;
+            if (rows > 0 && cols > 0) {
+                long long cnt = 0;
+                for (long long r = yp; r < y1; ++r) {
+                    const uint8_t* row = g.mask + (size_t)r * g.MW;
+                    for (long long c = xp; c < x1; ++c) cnt += row[c] != 0;
+                }
+                keep = (double)cnt / (double)(rows * cols) >= g.thresh;
+            }
+        }
+        flags[i] = keep;
+    }
+}
+__global__ __launch_bounds__(256) void tile_emit_kernel(TileGridArgs g, long long n, const int* flags, const int* excl, const int* block_sums, int* out_xy) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (!flags[i]) continue;
+        int x, y;
+        tile_at(g, i, x, y);
+        const long long o = (long long)excl[i] + block_sums[i >> 10];
+        out_xy[2 * o] = x; out_xy[2 * o + 1] = y;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dispatch
 static int grid_for(long long total) {
     long long g = (total + 255) / 256;
@@ -186,5 +232,33 @@ int wsi_kmeans_dispatch(const int* pts, int n, double* centres, int k, int iters
         if (!ch) break;                                       // no assignment changed: the centres are final
         hipLaunchKernelGGL(kmeans_update_kernel, dim3((k + 63) / 64), dim3(64), 0, st, centres, k, (const unsigned long long*)sums);
     }
+    return LAUNCH_OK();
+}
+
+static int range_len(int lo, int hi, int step) { return hi > lo ? (hi - lo + step - 1) / step : 0; }
+long long wsi_tile_grid_candidates_impl(int iw, int ih, int ph, int pw, int sh, int sw) {
+    if (sh <= 0 || sw <= 0) return -1;
+    const long long ny = range_len(1, ih - 1 - ph, sh), nx = range_len(1, iw - 1 - pw, sw);
+    return ny * nx + ny + nx;
+}
+size_t wsi_tile_grid_scratch_bytes_impl(long long n) { return (size_t)(2 * n + (n + 1023) / 1024 + 4) * sizeof(int); }
+int wsi_tile_grid_dispatch(int iw, int ih, int ph, int pw, int sh, int sw, const uint8_t* mask, int MH, int MW, double m, double thresh,
+                           int* out_xy, int* count_out, void* scratch, hipStream_t st) {
+    const long long n = wsi_tile_grid_candidates_impl(iw, ih, ph, pw, sh, sw);
+    if (n < 0 || n > 0x7ffffff0LL || ph <= 0 || pw <= 0 || (mask && (MH <= 0 || MW <= 0 || !(m > 0.0)))) return WSI_EINVAL;
+    if (n == 0) return hipMemsetAsync(count_out, 0, sizeof(int), st) == hipSuccess ? WSI_OK : WSI_EFAULT;
+    TileGridArgs g;
+    g.iw = iw; g.ih = ih; g.ph = ph; g.pw = pw; g.sh = sh; g.sw = sw;
+    g.ny = range_len(1, ih - 1 - ph, sh); g.nx = range_len(1, iw - 1 - pw, sw);
+    g.dx = (int)((double)pw * m); g.dy = (int)((double)ph * m);
+    g.MH = MH; g.MW = MW; g.m = m; g.thresh = thresh; g.mask = mask;
+    const long long nb = (n + 1023) / 1024;
+    int* flags = (int*)scratch;
+    int *excl = flags + n, *bsum = excl + n, *total = bsum + nb;
+    hipLaunchKernelGGL(tile_keep_kernel, dim3(grid_for(n)), dim3(256), 0, st, g, n, flags);
+    hipLaunchKernelGGL(scan_block_kernel, dim3((int)nb), dim3(256), 0, st, (const int*)flags, excl, bsum, n);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, bsum, (int)nb, total);
+    hipLaunchKernelGGL(tile_emit_kernel, dim3(grid_for(n)), dim3(256), 0, st, g, n, (const int*)flags, (const int*)excl, (const int*)bsum, out_xy);
+    if (hipMemcpyAsync(count_out, total, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return WSI_EFAULT;
     return LAUNCH_OK();
 }

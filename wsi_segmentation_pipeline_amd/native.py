@@ -88,6 +88,9 @@ SIGNATURES = {
     'wsi_connected_components_scratch_bytes': (_sz, [_i, _i]),
     'wsi_connected_components': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     'wsi_kmeans_points': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'wsi_tile_grid_candidates': (_ll, [_i, _i, _i, _i, _i, _i]),
+    'wsi_tile_grid_scratch_bytes': (_sz, [_ll]),
+    'wsi_tile_grid': (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     'wsi_exponent_span': (_i, [_vp, _ll, _vp, _vp]),
     'wsi_paint_regions': (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp]),
     'wsi_resize_bilinear_f64': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),

@@ -109,6 +109,36 @@ def tile_grid(iw, ih, ph, pw, sh, sw, mask=None, m=1.0, thresh=0.05):
     return np.stack([x, y], 1).astype(np.int32)
 
 
+def tile_grid_device(iw, ih, ph, pw, sh, sw, mask=None, m=1.0, thresh=0.05, device=None):
+    """tile_grid on the device (wsi_tile_grid): candidate enumeration, mask-window foreground test and order-preserving
+    compaction in HIP kernels; `mask` is a (MH,MW) uint8 GPU tensor (or ndarray, uploaded) or None.  Returns a (T,2) int32 GPU
+    tensor equal to tile_grid(...)."""
+    import ctypes as C
+    from . import native
+    from .engine import _ptr, _stream
+    lib = native.load()
+    dev = torch.device(device) if device is not None else (mask.device if isinstance(mask, torch.Tensor) else torch.device('cuda', torch.cuda.current_device()))
+    if dev.type != 'cuda':
+        raise RuntimeError('tile_grid_device runs on the GPU')
+    n = lib.wsi_tile_grid_candidates(iw, ih, ph, pw, sh, sw)
+    if n < 0:
+        raise ValueError('bad strides')
+    if n == 0:
+        return torch.zeros((0, 2), dtype=torch.int32, device=dev)
+    mk = None
+    if mask is not None:
+        mk = (mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask))).to(dev)
+        mk = (mk != 0).to(torch.uint8).contiguous()
+    out = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(lib.wsi_tile_grid_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        native.check(lib.wsi_tile_grid(iw, ih, ph, pw, sh, sw, _ptr(mk) if mk is not None else None, mk.shape[0] if mk is not None else 0,
+                                       mk.shape[1] if mk is not None else 0, float(m), float(thresh), _ptr(out), _ptr(count), _ptr(scratch),
+                                       _stream()), 'wsi_tile_grid')
+    return out[:int(count.item())]
+
+
 def map_coords(tile_xy, m):
     """int(m * x), int(m * y) in float64, as reference utils/eval.py:214."""
     return np.floor(np.asarray(tile_xy, np.float64) * m).astype(np.int32)
