@@ -255,7 +255,8 @@ def run_rank(args):
         # collected at batch 1000), scaled to this run's batch
         if not tj or batch is None:
             return None
-        sel = [v for k, v in tj['kernels'].items() if substr in k]
+        subs = (substr,) if isinstance(substr, str) else substr
+        sel = [v for k, v in tj['kernels'].items() if any(x in k for x in subs)]
         if not sel:
             return None
         return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / sum(v['launches'] for v in sel) * batch / 1000.0)
@@ -265,10 +266,10 @@ def run_rank(args):
         k = per_kind['conv3x3_s1']
         # Dominant kernel = the stride-1 3x3 conv of layers 2-4 (9 launches per batch); algorithmic FLOPs = 2*M*N*K over
         # real output pixels (302 MFLOP per conv and 256x256 patch); split passes are not counted
-        roofline = {'kernel': 'conv3x3s1_wide_kernel (9 launches per batch: the stride-1 3x3 convs of layers 2-4)',
+        roofline = {'kernel': 'stride-1 3x3 convs of layers 2-4, 9 launches per batch: conv3x3s1_pp_kernel (layers 3-4; parity mode: wide) + conv3x3s1_wide_kernel (layer 2)',
                     'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(k['tflops'] / PEAK_BF16_TFLOPS, 4),
-                    'traffic': pmc_bytes('conv3x3s1_wide', eff_batch),
+                    'traffic': pmc_bytes(('conv3x3s1_wide', 'conv3x3s1_pp'), eff_batch),
                     'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)' % (os.path.relpath(tpath, ROOT) if tj else 'not collected'),
                     'avg_launch_ms': round(k['avg_ms'], 4), 'mfma_passes': passes[planes], 'precision_mode': args.mode}
     l1 = per_kind.get('layer1_block_fused') or per_kind.get('conv3x3_s1_layer1')

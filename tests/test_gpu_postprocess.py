@@ -169,3 +169,16 @@ def test_predict_wsis_postprocess_matches_oracle(dev, tmp_path):
     sc['iou_tb'] = P.tumor_bed_iou(gt > 0, tb_pred)
     assert res['scores'] == sc, (res['scores'], sc)
     assert os.path.exists('%s/3/pp.svs_48.png' % a.val_save_pth)
+
+
+def test_contour_ordering_dropin(dev, golden_dir):
+    """The root-level `contour_ordering` module (the name the reference scripts import) returns the reference's golden
+    outputs for array-likes and CUDA tensors."""
+    import contour_ordering as co
+    g = np.load(os.path.join(golden_dir, 'esp.npz'))
+    got = co.evenly_spaced_points_on_a_contour(g['contour'], 16)
+    assert isinstance(got, np.ndarray) and np.abs(got - g['esp16']).max() <= 1e-12
+    got = co.evenly_spaced_points_on_a_contour(g['square'].tolist(), 9)
+    assert np.abs(got - g['esp_sq9']).max() <= 1e-12
+    t = co.evenly_spaced_points_on_a_contour(torch.from_numpy(g['contour']).to(dev), 8)
+    assert t.is_cuda and np.abs(t.cpu().numpy() - g['esp8']).max() <= 1e-12
