@@ -404,3 +404,29 @@ def test_stitch_exponent_guard(dev):
         E.check_stitch_exact(E.exponent_span(wide), 4)
     assert [int(t) for t in E.exponent_span(torch.zeros(5, device=dev)).cpu()] == [255, 0]
     E.check_stitch_exact(E.exponent_span(torch.zeros(5, device=dev)), 1000)
+
+
+def test_mx_clamp_to_fp16_range(dev):
+    """The documented deviation of mode 3: activations are clamped to the fp16 range (+-65504) when a conv writes its output
+    lines; parity mode carries the same values unclamped.  Centre-tap permutation weights of gain 300 on inputs up to 400
+    put outputs at up to 120000."""
+    from wsi_segmentation_pipeline_amd import engine as E
+    n, c, h, w = 2, 64, 8, 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(n, c, h, w, generator=g) * 400.0
+    wt = torch.zeros(c, c, 3, 3)
+    for co in range(c):
+        wt[co, (co * 7 + 3) % c, 1, 1] = 300.0 if co % 2 == 0 else -300.0
+    ref = F.conv2d(x, wt, None, 1, 1)
+    assert float(ref.abs().max()) > 100000
+    out = {}
+    for planes in (2, 3):
+        wpk, bias = E.prepack_conv(wt, None, planes, dev)
+        out[planes] = E.pf_unpack(E.conv_bn_act(E.pf_pack(x.to(dev), planes), n, h, w, c, c, wpk, bias, 1, 3, None, False, planes),
+                                  n, c, h, w, planes).cpu()
+    assert float((out[2] - ref).abs().max() / ref.abs().max()) <= TOL_PARITY               # parity: no clamp
+    clamped = ref.clamp(-65504.0, 65504.0)
+    assert float(out[3].abs().max()) == 65504.0
+    assert float((out[3] - clamped).abs().max() / 65504.0) <= TOL_MX
+    inside = ref.abs() < 60000
+    assert float((out[3][inside] - ref[inside]).abs().max() / 65504.0) <= TOL_MX
