@@ -95,6 +95,7 @@ struct ConvArgs {
     // (N,H,W,C) tensor, each a PF tensor of geometry (N,H/2,W/2,C), concatenated `*_split_pixels` pixels apart.
     // 0 = ordinary PF.  out_split_pixels: the epilogue writes `out` phase-split; in_split_pixels: `in` is phase-split.
     long long out_split_pixels, in_split_pixels;
+    int mtiles = 0;                      // set by launchers whose grid is rounded up: number of real pixel tiles
 };
 
 // ConvArgs.flags.  Product flags first; the CONV_ABL_* / study ones only act in builds with -DWSI_STUDY (bottleneck
