@@ -48,9 +48,11 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
 size_t wsi_prepack_stem_bytes(int planes);
 int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                      const float* bn_var, float eps, int planes, void* wpk_out, float* bias_out);
-/* Stem weights for u8 slide input (planes >= 2): the ToTensor + Normalize transform is folded in, so the kernel
- * multiplies the exact integers x - round(255 mean[c]) (one fp16 plane) by fp16 hi/lo weights: two MFMA passes
- * instead of three and no per-pixel table look-up.  Same byte size as wsi_prepack_stem_bytes(2). */
+/* Stem weights for u8 slide input (planes >= 2): ToTensor + Normalize (utils/preprocessing.py:209-212) and BN are folded into
+ * fixed-point weights (three balanced base-256 digits = 24 bits; one scale per output channel), so
+ * the kernel runs the 7x7 convolution in INTEGER arithmetic (v_mfma_i32_32x32x32_i8) on the bytes x - 128 plus an "inside"
+ * byte that makes zero padding exact: no per-pixel table look-up, exact i32 accumulation, one MFMA pass per digit.
+ * wpk_out: wsi_prepack_stem_bytes(2) bytes (opaque); bias_out: 64 floats. */
 int wsi_prepack_stem_u8(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                         const float* bn_var, float eps, const float mean[3], const float std_[3], int planes,
                         void* wpk_out, float* bias_out);

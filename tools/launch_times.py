@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--n', type=int, default=1000)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--tile', type=int, default=256, help='patch size (multiple of 32)')
+    ap.add_argument('--slide-tiles-per-row', type=int, default=0, help='tiles per slide row (default: square slide); 156 = the 40k-wide cfg3 slide, 1 = tiles stacked in one column (pitch 768 B)')
     ap.add_argument('--stem-rows', type=int, default=0, help='pooled rows per stem workgroup (default: library default)')
     ap.add_argument('--s2', type=int, default=-1, help='wsi_conv_set_mode value (0 gather, 1 slab with 64-pixel tiles, 3 slab with 128-pixel tiles)')
     args = ap.parse_args()
@@ -35,9 +36,10 @@ def main():
     cls = W.make_head_state_dict(22, 'classifier')
     eng = TrunkEngine(sd, dev, planes=args.planes, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.n)
     g = torch.Generator(device=dev).manual_seed(3)
-    side = int(np.ceil(np.sqrt(args.n)))
+    side = args.slide_tiles_per_row if args.slide_tiles_per_row > 0 else int(np.ceil(np.sqrt(args.n)))
     T = args.tile
-    slide = torch.randint(0, 256, (side * T, side * T, 3), dtype=torch.uint8, device=dev, generator=g)
+    rows_of_tiles = -(-args.n // side)
+    slide = torch.randint(0, 256, (rows_of_tiles * T, side * T, 3), dtype=torch.uint8, device=dev, generator=g)
     xy = torch.tensor([[T * (i % side), T * (i // side)] for i in range(args.n)], dtype=torch.int32, device=dev)
     eng.forward_tiles(slide, xy, T, T, logits=True)
     torch.cuda.synchronize()

@@ -245,45 +245,57 @@ int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bia
     return WSI_OK;
 }
 
-// Stem weights for the exact-u8 path: W' = W * bn_scale / (255 std[c]) * 2^8 as fp16 hi + fp16 lo (hi + lo == W' to
-// ~2^-22), bias' = bn_shift + sum_taps W * bn_scale / (255 std[c]) * (round(255 mean[c]) - 255 mean[c]), so that
-// sum W' (x - round(255 mean)) 2^-8 + bias' == conv(W, (x/255 - mean)/std) * bn_scale + bn_shift.  planes must be >= 2.
+// Stem weights for the integer (u8 slide) path, stem.hip stem_pool_kernel<.., DIG>: per output channel the folded weights
+//   w'(c, kh, kw) = W bn_scale / (255 std[c])            on the colour bytes (x - 128)
+//   k'(kh, kw)    = sum_c w'(c, kh, kw) (128 - 255 mean[c]) / 127      on the "inside" byte (127 inside the tile, 0 in the padding)
+// so that  sum w' (x - 128) + sum_inside 127 k' + bn_shift == conv(W, (x/255 - mean)/std) bn_scale + bn_shift  exactly,
+// written as fixed-point numbers q * scale[co] with q in DIG balanced base-256 digits (each an i8 in [-128, 127];
+// |q| <= 127 * 256^(DIG-1)), DIG = 3 (24 bits) in both split-precision modes.
+// Layout: [nt 2][kh 7][digit DIG][lane 64][16 B: k = 16 h + j -> kw = 4 h + (j >> 2), byte j & 3], then float scale[64]
+// at byte 2 * 7 * 3 * 1024 (inside the wsi_prepack_stem_bytes(2) buffer the callers allocate); bias_out = bn_shift.
 int wsi_prepack_stem_u8(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
                         const float* bn_var, float eps, const float mean[3], const float std_[3], int planes,
                         void* wpk_out, float* bias_out) {
     if (!w || !wpk_out || !bias_out || !mean || !std_ || planes < 2 || planes > 3) return WSI_EINVAL;
-    uint16_t* o = (uint16_t*)wpk_out;
-    double fold[3], dmean[3];
-    for (int c = 0; c < 3; ++c) {
-        fold[c] = 1.0 / (255.0 * (double)std_[c]);
-        dmean[c] = (double)lrintf(255.0f * mean[c]) - 255.0 * (double)mean[c];
-    }
+    const int DIG = 3;                                                        // stem.hip launches stem_pool_kernel<.., 3> in both modes
+    int8_t* o = (int8_t*)wpk_out;
+    float* scale_out = (float*)((char*)wpk_out + 2 * 7 * 3 * 1024);
+    memset(wpk_out, 0, (size_t)2 * 7 * 3 * 1024 + 64 * sizeof(float));
+    const double qmax = DIG == 3 ? 127.0 * 65536.0 : 127.0 * 256.0;
     for (int co = 0; co < 64; ++co) {
         double sc, sh;
         bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
-        double b = sh;
-        for (int c = 0; c < 3; ++c)
-            for (int t = 0; t < 49; ++t) b += (double)w[((size_t)co * 3 + c) * 49 + t] * sc * fold[c] * dmean[c];
-        bias_out[co] = (float)b;
-    }
-    for (int nt = 0; nt < 2; ++nt)
-        for (int s = 0; s < 14; ++s)
-            for (int p = 0; p < 2; ++p) {
-                uint16_t* frag = o + ((size_t)(nt * 14 + s) * 2 + p) * 512;
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int co = nt * 32 + (lane & 31), h = lane >> 5;
-                    double sc, sh;
-                    bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
-                    for (int j = 0; j < 8; ++j) {
-                        const int kh = s >> 1, kw = (s & 1) * 4 + 2 * h + (j >> 2), c = j & 3;
-                        double wd = 0.0;
-                        if (kw < 7 && c < 3) wd = (double)w[(((size_t)co * 3 + c) * 7 + kh) * 7 + kw] * sc * fold[c] * 256.0;
-                        const float hi = f16_round((float)wd);
-                        const float lo = f16_round((float)(wd - (double)hi));
-                        frag[lane * 8 + j] = f16_bits(p ? lo : hi);
+        bias_out[co] = (float)sh;
+        double val[7][8][4];                                                    // [kh][kw (7 -> 8)][colour bytes 0-2, inside byte 3]
+        double amax = 0.0;
+        for (int kh = 0; kh < 7; ++kh)
+            for (int kw = 0; kw < 8; ++kw) {
+                double kap = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    const double wd = kw < 7 ? (double)w[(((size_t)co * 3 + c) * 7 + kh) * 7 + kw] * sc / (255.0 * (double)std_[c]) : 0.0;
+                    val[kh][kw][c] = wd;
+                    kap += wd * (128.0 - 255.0 * (double)mean[c]);
+                    amax = fmax(amax, fabs(wd));
+                }
+                val[kh][kw][3] = kap / 127.0;
+                amax = fmax(amax, fabs(val[kh][kw][3]));
+            }
+        const double scale = amax > 0.0 ? amax / qmax : 1.0;
+        scale_out[co] = (float)scale;
+        const double fscale = (double)scale_out[co];                            // quantise against the fp32 scale the kernel multiplies by
+        const int nt = co >> 5, l31 = co & 31;
+        for (int kh = 0; kh < 7; ++kh)
+            for (int kw = 0; kw < 8; ++kw)
+                for (int c = 0; c < 4; ++c) {
+                    long long q = llround(val[kh][kw][c] / fscale);
+                    const int h = kw >> 2, j = (kw & 3) * 4 + c, lane = h * 32 + l31;
+                    for (int d = 0; d < DIG; ++d) {
+                        const long long dig = ((q + 128) & 255) - 128;           // balanced digit (two's-complement safe: & on negatives is modular)
+                        q = (q - dig) / 256;
+                        o[(((size_t)(nt * 7 + kh) * DIG + d) * 64 + lane) * 16 + j] = (int8_t)dig;
                     }
                 }
-            }
+    }
     return WSI_OK;
 }
 

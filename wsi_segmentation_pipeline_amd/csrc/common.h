@@ -193,10 +193,9 @@ struct StemArgs {
     const float* bias;         // 64
     float* out;                // [N][H/2][W/2][64] f32 (post ReLU)
     int N, H, W;               // patch size
-    // exact-u8 path of the fused kernel (mode 1, split precision): the pixel operand is the INTEGER x - offs[c]
-    // (exact in fp16), the normalisation 1/(255 std) is folded into fp16 hi/lo weights (x 2^8), the mean into the bias
-    const void* wpk_u8;        // [nt 2][s 14][plane 2][lane 64][8] fp16, or null: LUT path
+    // integer path of the fused kernel (mode 1, split precision): pixels as i8 (x - 128) + an inside byte, weights in balanced
+    // base-256 digits with the normalisation and BN folded in (capi.hip wsi_prepack_stem_u8, stem.hip stem_pool_kernel<.., DIG>)
+    const void* wpk_u8;        // [nt 2][kh 7][digit][lane 64][16] i8 + float scale[64], or null: LUT path
     const float* bias_u8;      // 64
-    float offs[3];             // round(255 mean[c])
-    float padv[3];             // 255 mean[c] - offs[c]: the value of a zero-padding pixel in this domain
+    float offs[3], padv[3];    // (unused since the integer stem; kept for the layout of the struct)
 };

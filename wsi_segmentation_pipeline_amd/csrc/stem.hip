@@ -188,10 +188,22 @@ constexpr int SP_RING = 16;                  // ring rows
 constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
 
 // PLANES = arithmetic of the stem itself (1: bf16, 2: bf16 hi/lo 3-pass); OUT = output line format (1, 2 or 3).
-// U8X (PLANES == 2, u8 slide input): the pixel operand is the exact integer x - round(255 mean) in ONE fp16 plane and
-// the weights carry the normalisation (fp16 hi/lo, x 2^8): two MFMA passes, result exact to ~2^-22 of the weights.
-template <int PLANES, int OUT, bool U8X = false>
+// U8X = DIG > 0 (u8 slide input, the product path): INTEGER arithmetic on v_mfma_i32_32x32x32_i8.  The pixel operand is the
+// exact byte quadruple (R - 128, G - 128, B - 128, inside ? 127 : 0) - 4 bytes per pixel in the LDS ring, one 16-byte
+// fragment = the four pixels (kw 4h .. 4h+3) of one kernel row, so K = 7 rows x 32 = 7 MFMA steps instead of 14.  The
+// weights carry the normalisation and BN: w' = w bn_scale / (255 std[c]) per colour channel and, on the fourth ("inside")
+// channel, kappa / 127 with kappa = sum_c w'_c (128 - 255 mean[c]) - so zero padding (all four bytes 0) contributes exactly
+// nothing and a black out-of-slide pixel (0, 0, 0 -> -128, inside) exactly what the reference computes.  Each output
+// channel's weights are fixed-point numbers in DIG = 3 balanced base-256 digits (24 bits, the precision of the fp32 weights
+// themselves), one i8 MFMA pass per digit into its own exact i32 accumulator, recombined in the epilogue:
+// (a2 2^16 + a1 2^8 + a0) scale[cout] + bn_shift[cout].  42 MFMAs of 32 cycles per pooled row and wave instead of the 56 of
+// the fp16 hi/lo form it replaces (r02: 2.52 -> 2.08 ms per 2000 patches; DIG = 2 measured the same 2.08 ms - the kernel is
+// then bound by its VALU epilogue - and 1.1-1.6x the logit error on the margin families, so it is not used).
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+constexpr int STEM_I8_SCALE_OFFSET = 2 * 7 * 3 * 1024;           // float scale[64] behind the digit planes (capi.hip: wsi_prepack_stem_u8)
+template <int PLANES, int OUT, int DIG = 0>
 __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
+    constexpr bool U8X = DIG > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const StemArgs& a = A.s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -215,15 +227,31 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     if (a.mode == 1) { tx = a.origins[2 * n]; ty = a.origins[2 * n + 1]; }
 
     // this wave's weights: [nt][ks][plane][lane][8] -> registers
-    bf16x8 wreg[14][PLANES];
+    constexpr int NKS = U8X ? 1 : 14, NDG = U8X ? DIG : 1;
+    bf16x8 wreg[NKS][PLANES];
+    i32x4 wq[U8X ? 7 : 1][NDG];
+    float bias[U8X ? 1 : 16];
+    // integer path: per-channel scale and shift live in LDS behind the (4-byte) ring and are read four at a time in the
+    // epilogue - 32 fewer live registers across the MFMA loop
+    float* const sb_lds = (float*)(smem + SP_RING * SP_COLS * 4);       // [scale 64][shift 64]
+    if constexpr (U8X) {
 #pragma unroll
-    for (int ks = 0; ks < 14; ++ks)
+        for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
-        for (int p = 0; p < PLANES; ++p)
-            wreg[ks][p] = *((const bf16x8*)(U8X ? a.wpk_u8 : a.wpk) + ((size_t)(wave * 14 + ks) * PLANES + p) * 64 + lane);
-    float bias[16];
+            for (int d = 0; d < DIG; ++d) wq[ks][d] = *((const i32x4*)a.wpk_u8 + ((size_t)(wave * 7 + ks) * DIG + d) * 64 + lane);
+        if (tid < 64) {
+            sb_lds[tid] = ((const float*)((const char*)a.wpk_u8 + STEM_I8_SCALE_OFFSET))[tid];
+            sb_lds[64 + tid] = a.bias_u8[tid];
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = (U8X ? a.bias_u8 : a.bias)[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
+        for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p)
+                wreg[ks][p] = *((const bf16x8*)a.wpk + ((size_t)(wave * 14 + ks) * PLANES + p) * 64 + lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = a.bias[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
+    }
     const size_t slide_bytes = (size_t)a.SH * (size_t)a.slide_pitch;
 
     auto stage_rows = [&](int row_lo, int nrows) {                      // input rows [row_lo, row_lo+nrows) -> ring
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
             const int slot = (iy + 64) & (SP_RING - 1);
             const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             if constexpr (U8X) {
-                f16x4 xv = {(_Float16)a.padv[0], (_Float16)a.padv[1], (_Float16)a.padv[2], (_Float16)0.f};
+                unsigned q = 0u;                                        // zero padding: contributes exactly nothing
                 if (inside) {
                     const int sx = tx + ix, sy = ty + iy;
                     unsigned rgb = 0u;                                  // outside the slide OpenSlide pads with black
@@ -243,10 +271,9 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                         if (off + 4 <= slide_bytes) __builtin_memcpy(&rgb, pp, 4);   // one (unaligned) dword: R, G, B, next R
                         else rgb = pp[0] | (pp[1] << 8) | (pp[2] << 16);             // last pixel of the buffer
                     }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) xv[c] = (_Float16)((float)((rgb >> (8 * c)) & 255u) - a.offs[c]);   // exact
+                    q = ((rgb & 0xffffffu) ^ 0x808080u) | 0x7f000000u;  // (R, G, B) - 128 as i8, inside = 127
                 }
-                *(f16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = xv;
+                *(unsigned*)(smem + (size_t)(slot * SP_COLS + cc) * 4) = q;
             } else {
                 float v[3] = {0.f, 0.f, 0.f};
                 if (inside) {
@@ -306,12 +333,9 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
             const int r = i / SP_COLS, cc = i - r * SP_COLS;
             const int iy = row_lo + r, ix = ix0 + cc;
             const int slot = (iy + 64) & (SP_RING - 1);
-            f16x4 xv = {(_Float16)a.padv[0], (_Float16)a.padv[1], (_Float16)a.padv[2], (_Float16)0.f};
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) xv[c] = (_Float16)((float)((pf_rgb[k] >> (8 * c)) & 255u) - a.offs[c]);
-            }
-            *(f16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = xv;
+            unsigned q = 0u;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) q = ((pf_rgb[k] & 0xffffffu) ^ 0x808080u) | 0x7f000000u;
+            *(unsigned*)(smem + (size_t)(slot * SP_COLS + cc) * 4) = q;
         }
     };
 
@@ -333,6 +357,27 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
             if (py + 1 < py1) stage_rows(4 * (py + 1) + 2, 4);         // rows the NEXT step adds (not read by this step)
         }
         f32x16 acc[2];
+        i32x16 aq[U8X ? 2 : 1][NDG];
+        if constexpr (U8X) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int d = 0; d < DIG; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) aq[mt][d][r] = 0;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {                            // one kernel row per step: 8 pixels x 4 bytes = K 32
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int slot = (4 * py + 2 * mt - 3 + ks + 64) & (SP_RING - 1);
+                    const char* xp = smem + (size_t)(slot * SP_COLS + 2 * lc + 4 * h) * 4;      // 8-byte aligned
+                    const uint2 x01 = *(const uint2*)xp, x23 = *(const uint2*)(xp + 8);
+                    const i32x4 x = {(int)x01.x, (int)x01.y, (int)x23.x, (int)x23.y};
+#pragma unroll
+                    for (int d = 0; d < DIG; ++d) aq[mt][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[ks][d], x, aq[mt][d], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -345,11 +390,6 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                 const int slot = (4 * py + 2 * mt - 3 + kh + 64) & (SP_RING - 1);
                 const char* xp = smem + (size_t)(slot * SP_COLS + 2 * lc + kw0) * 8;
                 const bf16x8 x0 = *(const bf16x8*)xp;
-                if constexpr (U8X) {
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[ks][1]), __builtin_bit_cast(f16x8, x0), acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[ks][0]), __builtin_bit_cast(f16x8, x0), acc[mt], 0, 0, 0);
-                    continue;
-                }
                 if constexpr (PLANES == 2) {
                     const bf16x8 x1 = *(const bf16x8*)(xp + SP_PLANE);
                     acc[mt] = mfma_bf16(wreg[ks][1], x0, acc[mt]);
@@ -358,14 +398,25 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                 acc[mt] = mfma_bf16(wreg[ks][0], x0, acc[mt]);
             }
         }
+        }
         // bias + ReLU + validity mask, vertical max with the carried row, keep row 2py+1 as the next carry
         const bool r0_ok = (2 * py) >= 0 && (2 * py) < Hc, r1_ok = (2 * py + 1) >= 0 && (2 * py + 1) < Hc;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            constexpr float ASC = U8X ? 1.0f / 256.0f : 1.0f;          // undo the 2^8 weight scale (exact)
-            const float a0 = (col_ok && r0_ok) ? fmaxf(acc[0][r] * ASC + bias[r], 0.f) : 0.f;
-            const float a1 = (col_ok && r1_ok) ? fmaxf(acc[1][r] * ASC + bias[r], 0.f) : 0.f;
+            float c0, c1, sh;
+            if constexpr (U8X) {                                        // exact recombination of the digit planes, then the channel's scale
+                const int l0 = DIG >= 2 ? aq[0][DIG >= 2 ? 1 : 0][r] * 256 + aq[0][0][r] : aq[0][0][r];
+                const int l1 = DIG >= 2 ? aq[1][DIG >= 2 ? 1 : 0][r] * 256 + aq[1][0][r] : aq[1][0][r];
+                c0 = (float)l0; c1 = (float)l1;
+                if constexpr (DIG == 3) { c0 = (float)aq[0][DIG - 1][r] * 65536.0f + c0; c1 = (float)aq[1][DIG - 1][r] * 65536.0f + c1; }
+                const int ch = wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                const float qs = sb_lds[ch];
+                sh = sb_lds[64 + ch];
+                c0 *= qs; c1 *= qs;
+            } else { c0 = acc[0][r]; c1 = acc[1][r]; sh = bias[r]; }
+            const float a0 = (col_ok && r0_ok) ? fmaxf(c0 + sh, 0.f) : 0.f;
+            const float a1 = (col_ok && r1_ok) ? fmaxf(c1 + sh, 0.f) : 0.f;
             v[r] = fmaxf(fmaxf(carry[r], a0), a1);
             carry[r] = a1;
         }
@@ -445,10 +496,10 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
     const bool u8x = a.mode == 1 && a.wpk_u8 && a.bias_u8 && planes >= 2;
     const size_t lds = (size_t)(planes == 1 || u8x ? 1 : 2) * SP_PLANE;
-    if (u8x && planes == 3)
-        hipLaunchKernelGGL((stem_pool_kernel<2, 3, true>), dim3((int)grid), dim3(128), lds, st, A);
+    if (u8x && planes == 3)                           // integer stem, 24-bit weights in both modes (r02: the 16-bit form, DIG 2, runs no
+        hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3>), dim3((int)grid), dim3(128), lds, st, A);   // faster - the kernel is VALU-bound - and costs mx margin)
     else if (u8x)
-        hipLaunchKernelGGL((stem_pool_kernel<2, 2, true>), dim3((int)grid), dim3(128), lds, st, A);
+        hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (planes == 3)                             // f32 input: bf16 hi/lo arithmetic, mode-3 output lines
         hipLaunchKernelGGL((stem_pool_kernel<2, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (planes == 2)
