@@ -134,8 +134,10 @@ def run_rank(args):
         raise SystemExit('bench.py needs a GPU: the inference path has no CPU fallback')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    dist_on = world > 1 or os.environ.get('WSI_FORCE_COLLECTIVE') == '1'      # (the latter: RCCL path rehearsal on one GPU)
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # "nccl" is RCCL on ROCm
 
     from wsi_segmentation_pipeline_amd import native, slide as S
@@ -155,7 +157,7 @@ def run_rank(args):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -261,7 +263,7 @@ def run_rank(args):
     fence()
     dt = time.perf_counter() - t0
     per_kind = collect_prof(lib, np, launches_per_step * args.steps, dt) if prof_on else {}
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -395,7 +397,7 @@ def run_rank(args):
                                    'algorithmic_bytes': 'threshold 8+1, open 30x30 4 passes x 2, hull 3, perimeter 2, dilate 2 passes x 2 = 27 B/px',
                                    'GBps': round(27 * npx / (ms * 1e-3) / 1e9, 1)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

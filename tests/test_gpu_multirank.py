@@ -124,3 +124,23 @@ def test_two_rank_region_bags_equal_single_rank():
     for p in procs:
         p.join(120)
     assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+
+
+@pytest.mark.parametrize('workload', ['cfg3', 'cfg4'])
+def test_rccl_path_rehearsal_single_rank(workload):
+    """The 'nccl' (= RCCL) code path of bench.py - init_process_group with device_id, device all_gather_into_tensor,
+    barrier, all_reduce(MAX), destroy - cannot run with two ranks on a one-GPU box, so it is rehearsed with ONE rank and
+    the collective forced (WSI_FORCE_COLLECTIVE=1): same calls, same tensors, a one-rank communicator.  The line must be
+    well-formed and the value plausible."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WSI_FORCE_COLLECTIVE='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    extra = ['--size', '6000'] if workload == 'cfg3' else ['--regions', '200']
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--workload', workload, '--steps', '1', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-bf16-leg'] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 1000 and line['scaling'] == 'strong'

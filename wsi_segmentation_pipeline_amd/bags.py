@@ -33,7 +33,8 @@ def gather_rows(local, shards, rank, world):
     padded chunks (payload R x C fp32: latency-bound, a single collective), then an index scatter."""
     import torch.distributed as dist
     total = sum(len(s) for s in shards)
-    if world == 1:
+    from .slide import _collective_forced
+    if world == 1 and not _collective_forced():
         out = torch.empty((total, local.shape[1]), dtype=local.dtype, device=local.device)
         out[torch.as_tensor(shards[0], device=local.device)] = local
         return out

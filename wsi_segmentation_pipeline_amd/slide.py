@@ -152,11 +152,18 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _collective_forced():
+    """WSI_FORCE_COLLECTIVE=1: issue the collective even for world == 1 (exercises the RCCL path on a one-GPU box)."""
+    import os
+    import torch.distributed as dist
+    return os.environ.get('WSI_FORCE_COLLECTIVE') == '1' and dist.is_available() and dist.is_initialized()
+
+
 def gather_tile_logits(local_logits, total, rank, world):
     """Concatenate per-rank logits in rank order on every rank.  One RCCL all-gather of equal-size
     padded chunks (payload = total x C fp32: latency-bound, a single collective)."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not _collective_forced():
         return local_logits
     c = local_logits.shape[1]
     chunk = (total + world - 1) // world
