@@ -49,8 +49,9 @@ def test_taps_vs_oracle_64(dev, sd, planes, tol):
 
 def test_u8_slide_path_equals_f32_path(dev, sd):
     """Fused tile read + transform in the stem == gather + normalise on the host side.  With the table look-up
-    arithmetic the two are bit-identical; the default exact-integer arithmetic (transform folded into fp16 hi/lo
-    weights, two MFMA passes) agrees to fp32 rounding and is the MORE accurate of the two against the fp32 oracle."""
+    arithmetic the two are bit-identical; the default INTEGER arithmetic (transform and BN folded into 24-bit fixed-point
+    weights, i8 MFMA with exact i32 accumulation) agrees to fp32 rounding and is the MORE accurate of the two against the
+    fp32 oracle."""
     from wsi_segmentation_pipeline_amd import native
     from wsi_segmentation_pipeline_amd.engine import TrunkEngine
     rng = np.random.default_rng(7)
@@ -85,6 +86,30 @@ def test_u8_slide_path_equals_f32_path(dev, sd):
         e_u8 = float((p_u8 - ref).abs().max() / ref.abs().max())
         print('planes=%d stem tap rel err vs oracle: f32 input path %.2e, u8 exact-integer path %.2e' % (planes, e_f32, e_u8))
         assert e_f32 <= (2e-5 if planes == 2 else 2e-4) and e_u8 <= (2e-5 if planes == 2 else 2e-4)
+
+
+def test_integer_stem_extreme_pixels(dev, sd):
+    """Saturated (255), black (0) and checkerboard 0/255 tiles, plus tiles leaving the slide on every side: the integer stem
+    (bytes x - 128 = -128 ... 127, inside byte, exact zero padding) against the fp32 oracle's pooled stem output."""
+    from oracle import wsi_oracle as WO
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    slide = np.zeros((192, 192, 3), np.uint8)
+    slide[:64] = 255
+    slide[64:128, :, 0] = 255
+    yy, xx = np.mgrid[:64, :192]
+    slide[128:] = (((yy + xx) % 2) * 255)[..., None]
+    xy = np.array([[0, 0], [64, 64], [128, 128], [-20, -30], [150, 160], [-40, 100], [100, -40]], np.int32)
+    tiles = np.stack([WO.read_tile(slide, int(x), int(y), 64, 64) for x, y in xy]).transpose(0, 3, 1, 2)
+    with torch.no_grad():
+        taps = {}
+        R.trunk(sd, R.normalize_u8(tiles), taps)
+    ref = taps['pool']
+    for planes, tol in ((2, 2e-5), (3, 2e-4)):
+        eng = TrunkEngine(sd, dev, planes=planes)
+        got = eng.forward_tiles(torch.from_numpy(slide).to(dev), torch.from_numpy(xy).to(dev), 64, 64, logits=False, tap=0).cpu()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        print('integer stem, extreme pixels, planes=%d: rel err %.2e' % (planes, err))
+        assert err <= tol
 
 
 def _bag(dev, sd, name, planes, golden_dir):

@@ -333,14 +333,9 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
     a.origins = tile_xy; a.lut = lut; a.wpk = stem_wpk; a.bias = stem_bias; a.out = scratch;
     a.N = n; a.H = h; a.W = w;
     a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
-    for (int c = 0; c < 3; ++c) { a.offs[c] = 0.f; a.padv[c] = 0.f; }
-    if (stem_wpk_u8 && stem_bias_u8 && norm_mean_std && !in_f32 && g_stem_u8x) {      // host pointer: mean[3], std[3]
-        a.wpk_u8 = stem_wpk_u8; a.bias_u8 = stem_bias_u8;
-        for (int c = 0; c < 3; ++c) {
-            a.offs[c] = (float)lrintf(255.0f * norm_mean_std[c]);
-            a.padv[c] = (float)(255.0 * (double)norm_mean_std[c] - (double)a.offs[c]);
-        }
-    }
+    // integer stem for u8 slide input (the transform is inside the packed weights; norm_mean_std is kept in the signature
+    // for ABI stability and as the caller's statement of which transform those weights carry)
+    if (stem_wpk_u8 && stem_bias_u8 && norm_mean_std && !in_f32 && g_stem_u8x) { a.wpk_u8 = stem_wpk_u8; a.bias_u8 = stem_bias_u8; }
     if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
@@ -994,7 +989,6 @@ int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights
     a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
     a.origins = tile_xy; a.lut = lut; a.wpk = wt->stem_w; a.bias = wt->stem_b; a.out = (float*)(ws + p.stem_scratch);
     a.N = n; a.H = h; a.W = w; a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
-    for (int c = 0; c < 3; ++c) { a.offs[c] = 0.f; a.padv[c] = 0.f; }
     rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
     if (!rc) rc = wsi_nhwc_to_pf_dispatch(a.out, dec + u.x0, n, h / 2, w / 2, 64, planes, st);
     if (rc) return rc;

@@ -197,5 +197,4 @@ struct StemArgs {
     // base-256 digits with the normalisation and BN folded in (capi.hip wsi_prepack_stem_u8, stem.hip stem_pool_kernel<.., DIG>)
     const void* wpk_u8;        // [nt 2][kh 7][digit][lane 64][16] i8 + float scale[64], or null: LUT path
     const float* bias_u8;      // 64
-    float offs[3], padv[3];    // (unused since the integer stem; kept for the layout of the struct)
 };
