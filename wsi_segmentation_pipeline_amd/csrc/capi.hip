@@ -312,11 +312,13 @@ int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_ou
 
 // ------------------------------------------------------------------------------------ single ops
 static int g_stem_fused = 1, g_stem_rows = 32;       // fused stem+maxpool kernel; pooled rows per workgroup
+extern int g_stem_shared_weights;                     // stem.hip
 static int g_stem_u8x = 1;                            // exact-u8 arithmetic when the caller supplies its weights (A/B: fused = 2 disables)
 
 int wsi_stem_set_mode(int fused, int rows_per_seg) {
     if (rows_per_seg <= 0) return WSI_EINVAL;
     g_stem_fused = fused ? 1 : 0; g_stem_rows = rows_per_seg; g_stem_u8x = fused != 2;
+    g_stem_shared_weights = fused != 3;                // 3: integer stem in its one-strip form (weights in registers), A/B
     return WSI_OK;
 }
 

@@ -201,13 +201,23 @@ constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
 // then bound by its VALU epilogue - and 1.1-1.6x the logit error on the margin families, so it is not used).
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 constexpr int STEM_I8_SCALE_OFFSET = 2 * 7 * 3 * 1024;           // float scale[64] behind the digit planes (capi.hip: wsi_prepack_stem_u8)
-template <int PLANES, int OUT, int DIG = 0>
-__global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
-    constexpr bool U8X = DIG > 0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// NSTRIP (integer path only): strips per workgroup.  1 = the form above, weights in registers (236 VGPRs, two waves per SIMD).
+// 2 = a 256-thread workgroup of two strips whose four waves share ONE copy of the digit planes in LDS (42 KB) and read each
+// weight fragment right before its MFMA: ~150 VGPRs, three waves per SIMD.  r02 counters of the 1-strip form: VALU active 68 %
+// + matrix pipe 32 % of the SIMD time with the waves waiting 25 % of their lifetime - more waves, not fewer instructions,
+// is what the kernel lacks.
+constexpr int SP_RING_I8 = SP_RING * SP_COLS * 4;                       // ring bytes of the integer path (4 B per pixel)
+template <int PLANES, int OUT, int DIG = 0, int NSTRIP = 1>
+__global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_kernel(StemPoolArgs A) {
+    constexpr bool U8X = DIG > 0, WLDS = NSTRIP > 1;
+    static_assert(!WLDS || U8X, "shared weights: integer path only");
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const StemArgs& a = A.s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = output-channel tile
+    const int tid = threadIdx.x & 127, lane = tid & 63;                 // tid: thread within the strip's wave pair
+    const int wave_g = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wave = wave_g & 1;                                        // = output-channel tile
+    const int sl = wave_g >> 1;                                         // strip within the workgroup
+    char* const smem = smem_all + (WLDS ? sl * SP_RING_I8 : 0);         // this strip's ring
     const int l31 = lane & 31, h = lane >> 5;
     const int Hc = a.H / 2, Wc = a.W / 2, Hp = a.H / 4, Wp = a.W / 4;
     // Strips: normally 15 pooled columns on the ODD lanes 1..29 (lane = conv column 2*px0 - 1 + lane: the column left of
@@ -215,7 +225,9 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     // conv column, pooled column p on lane 2p, whose left neighbour for p = 0 is the padding (lane 0 keeps its own value).
     const bool even = Wp <= 16;
     const int nstrips = even ? 1 : (Wp + 14) / 15, nsegs = (Hp + A.rows_per_seg - 1) / A.rows_per_seg;
-    int b = blockIdx.x;
+    const long long nstrips_total = (long long)a.N * nsegs * nstrips;
+    const bool strip_ok = (long long)blockIdx.x * NSTRIP + sl < nstrips_total;     // (a last workgroup may hold an idle strip)
+    int b = strip_ok ? (int)(blockIdx.x * NSTRIP + sl) : (int)(nstrips_total - 1);
     const int strip = b % nstrips; b /= nstrips;
     const int seg = b % nsegs;
     const int n = b / nsegs;
@@ -229,19 +241,24 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     // this wave's weights: [nt][ks][plane][lane][8] -> registers
     constexpr int NKS = U8X ? 1 : 14, NDG = U8X ? DIG : 1;
     bf16x8 wreg[NKS][PLANES];
-    i32x4 wq[U8X ? 7 : 1][NDG];
+    i32x4 wq[U8X && !WLDS ? 7 : 1][NDG];
     float bias[U8X ? 1 : 16];
     // integer path: per-channel scale and shift live in LDS behind the (4-byte) ring and are read four at a time in the
     // epilogue - 32 fewer live registers across the MFMA loop
-    float* const sb_lds = (float*)(smem + SP_RING * SP_COLS * 4);       // [scale 64][shift 64]
+    float* const sb_lds = (float*)(smem_all + NSTRIP * SP_RING_I8);     // [scale 64][shift 64]
+    char* const wl = smem_all + NSTRIP * SP_RING_I8 + 512;        // WLDS: the digit planes [nt 2][kh 7][digit][lane][16 B]
     if constexpr (U8X) {
+        if constexpr (WLDS) {
+            for (int i = threadIdx.x; i < 2 * 7 * DIG * 64; i += 128 * NSTRIP) ((uint4*)wl)[i] = ((const uint4*)a.wpk_u8)[i];
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 7; ++ks)
+            for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
-            for (int d = 0; d < DIG; ++d) wq[ks][d] = *((const i32x4*)a.wpk_u8 + ((size_t)(wave * 7 + ks) * DIG + d) * 64 + lane);
-        if (tid < 64) {
-            sb_lds[tid] = ((const float*)((const char*)a.wpk_u8 + STEM_I8_SCALE_OFFSET))[tid];
-            sb_lds[64 + tid] = a.bias_u8[tid];
+                for (int d = 0; d < DIG; ++d) wq[ks][d] = *((const i32x4*)a.wpk_u8 + ((size_t)(wave * 7 + ks) * DIG + d) * 64 + lane);
+        }
+        if (threadIdx.x < 64) {
+            sb_lds[threadIdx.x] = ((const float*)((const char*)a.wpk_u8 + STEM_I8_SCALE_OFFSET))[threadIdx.x];
+            sb_lds[64 + threadIdx.x] = a.bias_u8[threadIdx.x];
         }
     } else {
 #pragma unroll
@@ -350,7 +367,10 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     const size_t pixstride = (size_t)64 * PFmt<OUT>::BPC;
     PFGeom go = pf_geom(a.N, Hp, Wp, 64);
 
-    for (int py = py0 - 1; py < py1; ++py) {
+    // every wave of the workgroup makes the same number of trips (one barrier each); strips with fewer rows idle at the end
+    for (int it = 0; it <= A.rows_per_seg; ++it) {
+        const int py = py0 - 1 + it;
+        if (!strip_ok || py >= py1) { __syncthreads(); continue; }
         if constexpr (U8X) {
             if (py + 1 < py1) fetch_rows(4 * (py + 1) + 2);            // rows the NEXT step adds: loads in flight
         } else {
@@ -374,7 +394,12 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
                     const uint2 x01 = *(const uint2*)xp, x23 = *(const uint2*)(xp + 8);
                     const i32x4 x = {(int)x01.x, (int)x01.y, (int)x23.x, (int)x23.y};
 #pragma unroll
-                    for (int d = 0; d < DIG; ++d) aq[mt][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[ks][d], x, aq[mt][d], 0, 0, 0);
+                    for (int d = 0; d < DIG; ++d) {
+                        i32x4 wv;
+                        if constexpr (WLDS) wv = *(const i32x4*)(wl + ((wave * 7 + ks) * DIG + d) * 1024 + lane * 16);
+                        else wv = wq[ks][d];
+                        aq[mt][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wv, x, aq[mt][d], 0, 0, 0);
+                    }
                 }
             }
         } else {
@@ -487,6 +512,7 @@ __global__ __launch_bounds__(128, 2) void stem_pool_kernel(StemPoolArgs A) {
     }
 }
 
+int g_stem_shared_weights = 1;                        // A/B: wsi_stem_set_mode(fused = 3) selects the one-strip form (weights in registers)
 int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st) {
     if (a.H % 4 || a.W % 4 || a.N <= 0 || planes < 1 || planes > 3 || rows_per_seg <= 0) return WSI_EINVAL;
     StemPoolArgs A;
@@ -496,8 +522,13 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
     const bool u8x = a.mode == 1 && a.wpk_u8 && a.bias_u8 && planes >= 2;
     const size_t lds = (size_t)(planes == 1 || u8x ? 1 : 2) * SP_PLANE;
-    if (u8x && planes == 3)                           // integer stem, 24-bit weights in both modes (r02: the 16-bit form, DIG 2, runs no
-        hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3>), dim3((int)grid), dim3(128), lds, st, A);   // faster - the kernel is VALU-bound - and costs mx margin)
+    if (u8x && g_stem_shared_weights) {               // integer stem, two strips per workgroup, digit planes shared in LDS
+        const size_t lds2 = 2 * SP_RING_I8 + 512 + 2 * 7 * 3 * 1024;
+        const int grid2 = (int)((grid + 1) / 2);
+        if (planes == 3) hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3, 2>), dim3(grid2), dim3(256), lds2, st, A);
+        else hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3, 2>), dim3(grid2), dim3(256), lds2, st, A);
+    } else if (u8x && planes == 3)                    // integer stem, 24-bit weights in both modes (r02: the 16-bit form, DIG 2, costs mx margin)
+        hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (u8x)
         hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (planes == 3)                             // f32 input: bf16 hi/lo arithmetic, mode-3 output lines
