@@ -212,6 +212,30 @@ def test_unfused_reference_kernels_agree(dev, sd):
     assert float((alt - base).abs().max()) <= 1e-4
 
 
+def test_integer_stem_forms_bit_identical(dev, sd):
+    """The two launch forms of the integer stem - one strip per workgroup with the digit planes in registers
+    (wsi_stem_set_mode(3, rows)) and two strips sharing them in LDS (default) - run the same arithmetic in the same order:
+    bit-identical pooled outputs, including an odd number of strips (a half-filled last workgroup) and short segments."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    rng = np.random.default_rng(17)
+    slide = torch.from_numpy(rng.integers(0, 256, (700, 900, 3), dtype=np.uint8)).to(dev)
+    for planes in (2, 3):
+        eng = TrunkEngine(sd, dev, planes=planes)
+        for tile, n in ((256, 3), (64, 5), (192, 1)):                   # 5 strips x 2 segments x 3; 1 strip x 1 x 5; 4 strips x 2 segments
+            xy = torch.from_numpy(rng.integers(-30, 600, (n, 2)).astype(np.int32)).to(dev)
+            for rows in (32, 7):
+                try:
+                    native.check(lib.wsi_stem_set_mode(1, rows), 'stem mode')
+                    a = eng.forward_tiles(slide, xy, tile, tile, logits=False, tap=0).clone()
+                    native.check(lib.wsi_stem_set_mode(3, rows), 'stem mode')
+                    b = eng.forward_tiles(slide, xy, tile, tile, logits=False, tap=0).clone()
+                finally:
+                    lib.wsi_stem_set_mode(1, 32)
+                assert torch.equal(a, b), (planes, tile, n, rows)
+
+
 def test_ab_switches_agree(dev, sd):
     """Every A/B route of wsi_conv_set_mode (phase-slab vs wide stride-2 kernel, slab3 vs wide stride-1 kernel, XCD
     orders, 128-pixel stride-2 tiles) gives the same logits up to summation order."""

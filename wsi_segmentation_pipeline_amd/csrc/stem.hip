@@ -434,11 +434,12 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 const int l0 = DIG >= 2 ? aq[0][DIG >= 2 ? 1 : 0][r] * 256 + aq[0][0][r] : aq[0][0][r];
                 const int l1 = DIG >= 2 ? aq[1][DIG >= 2 ? 1 : 0][r] * 256 + aq[1][0][r] : aq[1][0][r];
                 c0 = (float)l0; c1 = (float)l1;
-                if constexpr (DIG == 3) { c0 = (float)aq[0][DIG - 1][r] * 65536.0f + c0; c1 = (float)aq[1][DIG - 1][r] * 65536.0f + c1; }
+                if constexpr (DIG == 3) { c0 = __builtin_fmaf((float)aq[0][DIG - 1][r], 65536.0f, c0); c1 = __builtin_fmaf((float)aq[1][DIG - 1][r], 65536.0f, c1); }
                 const int ch = wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                 const float qs = sb_lds[ch];
                 sh = sb_lds[64 + ch];
-                c0 *= qs; c1 *= qs;
+                c0 = __builtin_fmaf(c0, qs, sh); c1 = __builtin_fmaf(c1, qs, sh);       // explicit FMAs (the build runs with -ffp-contract=off)
+                sh = 0.f;
             } else { c0 = acc[0][r]; c1 = acc[1][r]; sh = bias[r]; }
             const float a0 = (col_ok && r0_ok) ? fmaxf(c0 + sh, 0.f) : 0.f;
             const float a1 = (col_ok && r1_ok) ? fmaxf(c1 + sh, 0.f) : 0.f;
@@ -449,10 +450,12 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
             // horizontal 3-max: pooled column px0+j sits on odd lane 2j+1 of each 32-lane half
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                               // neighbours by DPP wave shifts (VALU, no LDS crossbar)
+                // (bound_ctrl: a lane without a source reads 0 - the neutral element, every value here is >= 0 after the ReLU - so
+                // no copy of the old value is needed and the shifts fold into the max instructions as DPP operands)
                 const int vi = __builtin_bit_cast(int, v[r]);
-                float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xf, 0xf, false));         // lane i <- i-1
-                if (even && l31 == 0) up = v[r];                         // even layout: column -1 is padding (lane 32 must not see lane 31)
-                const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xf, 0xf, false));   // lane i <- i+1
+                float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x138, 0xf, 0xf, true));          // lane i <- i-1
+                if (even && l31 == 0) up = 0.f;                          // even layout: column -1 is padding (lane 32 must not see lane 31)
+                const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x130, 0xf, 0xf, true));    // lane i <- i+1
                 v[r] = fmaxf(v[r], fmaxf(up, dn));
             }
             const int j = even ? (l31 >> 1) : ((l31 - 1) >> 1), px = px0 + j;
