@@ -69,6 +69,7 @@ def _conv_case(dev, n, cin, cout, h, w, stride, ksize, resid, relu, planes, seed
 CONV_S1 = [  # n, cin, cout, h, w
     (3, 64, 64, 16, 16), (2, 64, 64, 64, 64), (5, 128, 128, 8, 8), (2, 128, 128, 32, 32),
     (3, 256, 256, 4, 4), (2, 256, 256, 16, 16), (7, 512, 512, 2, 2), (3, 512, 512, 8, 8), (1, 64, 128, 8, 8),
+    (2, 64, 64, 12, 256), (1, 64, 64, 5, 130), (1, 128, 64, 6, 200),        # maps wider than 128: the 512-pixel slab3 tiles (cfg 39)
 ]
 
 

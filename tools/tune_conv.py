@@ -30,12 +30,14 @@ def main():
     ap.add_argument('--wcopies', type=int, default=1, help='study: replicate the packed weights N times (<= 16), workgroups spread over the copies')
     ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
     ap.add_argument('--shapes', type=str, default='', help='comma list of indices into SHAPES')
+    ap.add_argument('--shape', type=str, default='', help='one explicit C,H,W shape (e.g. 64,256,256: the U-Net decoder\'s last level)')
     args = ap.parse_args()
     lib = native.load()
     dev = torch.device('cuda:0')
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(0)
-    for (c, h, w) in ([SHAPES[int(i)] for i in args.shapes.split(',')] if args.shapes else SHAPES):
+    shapes = [tuple(int(v) for v in args.shape.split(','))] if args.shape else ([SHAPES[int(i)] for i in args.shapes.split(',')] if args.shapes else SHAPES)
+    for (c, h, w) in shapes:
         h, w = h // args.scale, w // args.scale
         n = args.n
         x = torch.randn(n, c, h, w, generator=g).abs_()

@@ -1383,6 +1383,9 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     // product build: only the tuned configurations are instantiated (cfg 30 / 31: slab3 for 128-multiple / 64-channel outputs)
     if (cfg == 30) return planes == 3 ? launch_slab3<4, 1, 4, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 1, 4, 2, 2, true>(a, st) : launch_slab3<4, 1, 4, 1, 2, true>(a, st);
     if (cfg == 31) return planes == 3 ? launch_slab3<4, 2, 2, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 2, 2, 2, 2, true>(a, st) : launch_slab3<4, 2, 2, 1, 2, true>(a, st);
+    // cfg 39: 512 px x 64 couts (4 x 2 waves) for 64-channel layers on maps wider than 128 (the U-Net decoder's last level): a
+    // 256-pixel tile of a 256-wide map is ONE row under a three-row slab; two rows per tile cut the halo from 3x to 2x
+    if (cfg == 39) return planes == 3 ? launch_slab3<4, 4, 2, 3, 1, true>(a, st) : planes == 2 ? launch_slab3<4, 4, 2, 2, 1, true>(a, st) : launch_slab3<4, 4, 2, 1, 1, true>(a, st);
 #endif
     return WSI_EINVAL;
 }
@@ -1395,6 +1398,7 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     // slab3 in single-pass bf16; bit-identical).  It needs two slabs in LDS: maps wider than 33 fall back.
     if (!fallback && planes != 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
     if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
+    if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
     return a.go.C % 128 == 0 ? 30 : 31;
 }
 
