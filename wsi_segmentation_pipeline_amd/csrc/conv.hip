@@ -1396,6 +1396,9 @@ int g_wide_min_c = 128;                                  // channel count from w
 static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {           // r01 / r02 tunes: profiles/r0*_tune_conv*.log
     // 256-multiple outputs (layers 3-4): the 8-wave ping-pong kernel (r02: +1...4 % over the wide kernel in mx, +4...7 % over
     // slab3 in single-pass bf16; bit-identical).  It needs two slabs in LDS: maps wider than 33 fall back.
+    // maps up to 4 x 4 (64 x 64 crops of the region-bag path: 25-56 % of a slab is padding): the small slab3 tiles keep four
+    // workgroups per CU where the wide / ping-pong slabs leave one (r02 tune, n = 32000: 1.13 vs 1.28 ms at 4 x 4, 0.94 vs 1.15 at 2 x 2)
+    if (a.gi.W <= 4 && a.go.C % 128 == 0 && planes == 3) return 30;
     if (!fallback && planes != 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
     if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
