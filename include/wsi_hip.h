@@ -38,7 +38,8 @@ long long wsi_pf_pixel_index(int n, int y, int x, int h, int w);
 /* ---- weight prepack (host, CPU memory in and out) -------------------------------------------
  * Folds eval-mode BatchNorm (resnets_shift.py:42,45,124; eps 1e-5) into the conv weights and
  * emits them in per-lane MFMA operand order.  bn_* may be NULL (no BN: scale 1, bias 0).
- *   conv: w OIHW fp32 [cout][cin][k][k], k in {1,3}, cin % 64 == 0, cout % 32 == 0
+ *   conv: w OIHW fp32 [cout][cin][k][k], k in {1,3}, cout % 32 == 0, cin a whole number of 128-byte lines (cin % 64 == 0 for
+ *         planes 1, cin % 32 == 0 for planes 2 / 3; 32-channel tensors are served by the stride-1 3x3 convolution only)
  *         wpk_out: wsi_prepack_conv_bytes() bytes; bias_out: cout floats
  *   stem: w [64][3][7][7] (resnets_shift.py:122)  */
 size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes);

@@ -84,6 +84,17 @@ def test_conv3x3_stride1(dev, shape):
     assert max(e3) <= TOL_MX
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 32, 40, 72), (1, 128, 32, 20, 130), (3, 32, 32, 9, 300), (1, 64, 32, 33, 64)])
+def test_conv3x3_32_channel_lines(dev, shape):
+    """Split-precision tensors of 32 channels (one 128-byte line): the stride-1 3x3 kernel with 32-output-channel tiles (cfg 90,
+    U-Net decoder levels 4-5); speed mode keeps 64-channel lines and refuses them."""
+    n, cin, cout, h, w = shape
+    assert _conv_case(dev, n, cin, cout, h, w, 1, 3, False, True, 2, 11) <= TOL_PARITY
+    assert _conv_case(dev, n, cin, cout, h, w, 1, 3, False, True, 3, 12) <= TOL_MX
+    from wsi_segmentation_pipeline_amd import native
+    assert native.load().wsi_prepack_conv_bytes(cout, 32, 3, 1) == 0
+
+
 CONV_S2 = [(3, 64, 128, 16, 16), (2, 64, 128, 64, 64), (3, 128, 256, 8, 8), (2, 256, 512, 16, 16), (5, 256, 512, 4, 4)]
 
 

@@ -127,7 +127,7 @@ long long wsi_pf_pixel_index(int n, int y, int x, int h, int w) {
 }
 
 size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes) {
-    if (cout % 32 || cin % 64 || (k != 1 && k != 3) || planes < 1 || planes > 3) return 0;
+    if (planes < 1 || planes > 3 || cout % 32 || cin % (planes == 1 ? 64 : 32) || (k != 1 && k != 3)) return 0;     // (whole 128-byte lines)
     // [cout/32][lines][k*k][4 frags][64 lanes][16 bytes]; lines = cin/64 (planes 1) or cin/32 (planes 2, 3)
     return (size_t)(cout / 32) * (planes == 1 ? cin / 64 : cin / 32) * k * k * 4 * 64 * 16;
 }
@@ -492,12 +492,12 @@ int wsi_linear(const float* x, const float* w, const float* bias, float* y, int 
 }
 
 int wsi_pf_pack(const float* in_nchw, void* out_pf, int n, int c, int h, int w, int planes, void* stream) {
-    if (!in_nchw || !out_pf || n <= 0 || c % 64 || planes < 1 || planes > 3) return WSI_EINVAL;
+    if (!in_nchw || !out_pf || n <= 0 || planes < 1 || planes > 3 || c % (planes == 1 ? 64 : 32)) return WSI_EINVAL;
     return wsi_pf_pack_dispatch(in_nchw, out_pf, pf_geom(n, h, w, c), planes, (hipStream_t)stream);
 }
 
 int wsi_pf_unpack(const void* in_pf, float* out_nchw, int n, int c, int h, int w, int planes, void* stream) {
-    if (!in_pf || !out_nchw || n <= 0 || c % 64 || planes < 1 || planes > 3) return WSI_EINVAL;
+    if (!in_pf || !out_nchw || n <= 0 || planes < 1 || planes > 3 || c % (planes == 1 ? 64 : 32)) return WSI_EINVAL;
     return wsi_pf_unpack_dispatch(in_pf, out_nchw, pf_geom(n, h, w, c), planes, (hipStream_t)stream);
 }
 
@@ -909,7 +909,8 @@ int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, cons
 
 // ------------------------------------------------------------------------------------ U-Net (dense 'seg' path)
 // smp-style decoder on the ResNet-18 trunk: five blocks of [nearest x2 upsample, concat skip, 2 x (3x3 conv + BN + ReLU)]
-// at channels 256/128/64/32/16 (stored padded to 64-multiples: the padding channels carry zero weights), 1x1 head.
+// at channels 256/128/64/32/16 (stored padded to whole 128-byte lines - 32 channels in the split-precision modes, 64 in
+// speed mode; the padding channels carry zero weights), 1x1 head.
 static const int kUnetSkipC[5] = {256, 128, 64, 64, 0};      // encoder maps x3, x2, x1, x0 (and none for the last block)
 struct UnetPlan {
     size_t x0, cat[5], mid[5], out[5], total;
@@ -923,7 +924,7 @@ static int unet_plan(const wsi_unet_decoder_weights* dw, int n, int h, int w, in
     for (int L = 0; L < 5; ++L) {
         u.r_h[L] = (h / 16) << L; u.r_w[L] = (w / 16) << L; u.cx[L] = cprev;
         const int cin = cprev + kUnetSkipC[L], cout = dw->cout[2 * L];
-        if (dw->cin[2 * L] != cin || dw->cin[2 * L + 1] != cout || dw->cout[2 * L + 1] != cout || cout % 64 || cout <= 0) return WSI_EINVAL;
+        if (dw->cin[2 * L] != cin || dw->cin[2 * L + 1] != cout || dw->cout[2 * L + 1] != cout || cout % (planes == 1 ? 64 : 32) || cout <= 0) return WSI_EINVAL;
         u.cat[L] = off; off += align_up(wsi_pf_bytes(n, u.r_h[L], u.r_w[L], cin, planes), 256);
         u.mid[L] = off; off += align_up(wsi_pf_bytes(n, u.r_h[L], u.r_w[L], cout, planes), 256);
         u.out[L] = off; off += align_up(wsi_pf_bytes(n, u.r_h[L], u.r_w[L], cout, planes), 256);

@@ -1342,9 +1342,13 @@ int wsi_pp_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);    
 int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
-    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || (cfg >= 70 && cfg < 80)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
+    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 80)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
     if (cfg >= 70 && cfg < 80) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
+    // cfg 90: 512 px x 32 couts (8 x 1 waves, two pixel tiles each) for 32-channel outputs (U-Net decoder levels 4-5)
+    if (cfg == 90) return planes == 3 ? launch_slab3<2, 8, 1, 3, 1, true>(a, st) : planes == 2 ? launch_slab3<2, 8, 1, 2, 1, true>(a, st) : WSI_EINVAL;
+    // cfg 91: 256 px x 32 couts, the fallback where a 512-pixel tile's slab exceeds the LDS (tiles straddling two images of a wide map)
+    if (cfg == 91) return planes == 3 ? launch_slab3<2, 4, 1, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<2, 4, 1, 2, 2, true>(a, st) : WSI_EINVAL;
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
 #ifdef WSI_STUDY
     if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
@@ -1396,6 +1400,7 @@ int g_wide_min_c = 128;                                  // channel count from w
 static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {           // r01 / r02 tunes: profiles/r0*_tune_conv*.log
     // 256-multiple outputs (layers 3-4): the 8-wave ping-pong kernel (r02: +1...4 % over the wide kernel in mx, +4...7 % over
     // slab3 in single-pass bf16; bit-identical).  It needs two slabs in LDS: maps wider than 33 fall back.
+    if (a.go.C % 64) return fallback ? 91 : 90;              // 32 output channels
     // maps up to 4 x 4 (64 x 64 crops of the region-bag path: 25-56 % of a slab is padding): the small slab3 tiles keep four
     // workgroups per CU where the wide / ping-pong slabs leave one (r02 tune, n = 32000: 1.13 vs 1.28 ms at 4 x 4, 0.94 vs 1.15 at 2 x 2)
     if (a.gi.W <= 4 && a.go.C % 128 == 0 && planes == 3) return 30;
@@ -1408,7 +1413,10 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
 // Host dispatch.  cfg < 0 selects the tuned default.
 int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     const int cout = a.go.C;
-    if (a.gi.C % 64 || cout % 64 || planes < 1 || planes > 3) return WSI_EINVAL;
+    if (planes < 1 || planes > 3) return WSI_EINVAL;
+    const int cmul = planes == 1 ? 64 : 32;                  // whole 128-byte lines; 32-channel tensors: stride-1 3x3 only (cfg 90)
+    if (a.gi.C % cmul || cout % cmul) return WSI_EINVAL;
+    if ((a.gi.C % 64 || cout % 64) && !(a.ksize == 3 && a.stride == 1)) return WSI_EINVAL;
     if (planes == 3 && !(a.ksize == 3 && a.stride == 1)) return WSI_EINVAL;      // mode 3: slab kernels only
     if (a.ksize == 3 && a.stride == 1) {
         if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;

@@ -73,7 +73,8 @@ class UNetEngine:
 
         cprev_real, cprev_pad = 512, 512
         for L in range(5):
-            cout, cout_pad = DEC_CH[L], _pad64(DEC_CH[L])
+            cout = DEC_CH[L]
+            cout_pad = _pad64(cout) if planes == 1 else -(-cout // 32) * 32        # whole 128-byte lines: 64 channels in speed mode, 32 otherwise
             for j in range(2):
                 p = 'decoder.layer%d.block.%d.block' % (L + 1, j)
                 w = f32(p + '.0.weight')
