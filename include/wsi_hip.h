@@ -74,7 +74,8 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
 
 /* tuning / A-B hook: fused = 1 (default) runs the single fused stem+maxpool kernel (no fp32
  * intermediate; scratch unused), fused = 0 the two-kernel form, fused = 2 the fused kernel with the table
- * look-up arithmetic even when u8 weights are supplied; rows_per_seg = pooled rows per workgroup of the
+ * look-up arithmetic even when u8 weights are supplied, fused = 3 the integer stem in its one-strip launch form (digit
+ * planes in registers instead of shared in LDS; bit-identical); rows_per_seg = pooled rows per workgroup of the
  * fused kernel (default 32).  Process-wide. */
 int wsi_stem_set_mode(int fused, int rows_per_seg);
 
