@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsi_segmentation_pipeline_amd import engine as E, native  # noqa: E402
 
 SHAPES = [(64, 64, 64), (128, 32, 32), (256, 16, 16), (512, 8, 8)]      # (C, H, W) for 256x256 patches
-NCFG = 80
+NCFG = 92
 
 
 def main():

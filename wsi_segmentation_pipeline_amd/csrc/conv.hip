@@ -1342,9 +1342,9 @@ int wsi_pp_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);    
 int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
-    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 80)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
+    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 90)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
-    if (cfg >= 70 && cfg < 80) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
+    if (cfg >= 70 && cfg < 90) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
     // cfg 90: 512 px x 32 couts (8 x 1 waves, two pixel tiles each) for 32-channel outputs (U-Net decoder levels 4-5)
     if (cfg == 90) return planes == 3 ? launch_slab3<2, 8, 1, 3, 1, true>(a, st) : planes == 2 ? launch_slab3<2, 8, 1, 2, 1, true>(a, st) : WSI_EINVAL;
     // cfg 91: 256 px x 32 couts, the fallback where a 512-pixel tile's slab exceeds the LDS (tiles straddling two images of a wide map)
@@ -1405,6 +1405,10 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     // workgroups per CU where the wide / ping-pong slabs leave one (r02 tune, n = 32000: 1.13 vs 1.28 ms at 4 x 4, 0.94 vs 1.15 at 2 x 2)
     if (a.gi.W <= 4 && a.go.C % 128 == 0 && planes == 3) return 30;
     if (!fallback && planes != 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
+    // parity mode (r02 tune, n = 2000): the ping-pong kernel in its 256 px x 128 couts shape on layers 3-4 (1.48 / 1.38 vs 1.55 / 1.43 ms
+    // for the wide kernel), slab3 on layer 2 (1.69 vs 1.78 ms)
+    if (!fallback && planes == 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 83;
+    if (planes == 2 && a.go.C == 128 && a.gi.W > 8 && g_wide_min_c <= 128) return 30;
     if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
     return a.go.C % 128 == 0 ? 30 : 31;

@@ -294,7 +294,10 @@ int wsi_pp_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
     case 75: return planes == 3 ? launch_pp<3, 2, 4, 4, true>(a, st) : WSI_EINVAL;       // cfg 70 with phase stamps (a.out2 = 512-byte debug buffer)
     case 76: return planes == 3 ? launch_pp<3, 4, 2, 3, true>(a, st) : WSI_EINVAL;       // cfg 71 with phase stamps
     case 79: return planes == 3 ? launch_pp<3, 8, 1, 1>(a, st) : WSI_EINVAL;             // 256 px x 64 couts (layer 1 study)
+    case 82: return planes == 2 ? launch_pp<2, 2, 4, 3>(a, st) : WSI_EINVAL;             // parity mode: 192 px x 256 couts (MT 4 spills)
+    case 84: return planes == 2 ? launch_pp<2, 2, 4, 2>(a, st) : WSI_EINVAL;             // parity mode: 128 px x 256 couts
 #endif
+    case 83: return planes == 2 ? launch_pp<2, 4, 2, 2>(a, st) : WSI_EINVAL;             // parity mode: 256 px x 128 couts (MT 4 spills there)
     case 72: return planes == 3 ? launch_pp<3, 2, 4, 4, false, 0, true>(a, st) : planes == 1 ? launch_pp<1, 2, 4, 4, false, 0, true>(a, st) : WSI_EINVAL;   // A/B: raised priority in the multiply phase
     }
     return WSI_EINVAL;
