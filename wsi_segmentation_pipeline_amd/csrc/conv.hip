@@ -168,7 +168,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             valid[mt] = pf_is_pixel(a.go, qs[mt]);
         }
     }
-    const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
+    static_assert((NTHREADS / 8) % 16 == 0, "whole swizzle periods per DMA round");
+    const size_t slab_byte0 = (size_t)slab0 * in_pixstride;
+    const size_t in_bytes = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * in_pixstride;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.in + slab_byte0), 0, (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000);
+    int xvoff;
+    {
+        const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+        xvoff = Pl * (int)in_pixstride + sl * 16;
+    }
     // study hook (tools/tune_conv.py --wcopies): bits 10-13 of relu = number of back-to-back copies of the packed
     // weights minus one; workgroups spread over the copies (do hot weight lines serialise on few L2 channels?)
     const size_t wcopy = (size_t)(mtile % ((CONV_STUDY(a, 15 << CONV_WCOPIES_SHIFT) >> CONV_WCOPIES_SHIFT) + 1)) * (size_t)(a.go.C / 32) * NC * 9 * 4096;
@@ -200,12 +209,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         bf16x8 wbuf[3][4], xf[2][4];
         wload(wbuf[0], sline);                                // W(c,0) flies during the slab DMA
         if (c) __syncthreads();
-        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
-            const int i = i0 + lane;
-            const int Pl = i >> 3, sp = i & 7;
-            const int s = sp ^ ((Pl >> 1) & 7);
-            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + s * 16, smem + (size_t)i0 * 16);
-        }
+        // slab pieces by buffer addressing: a round of NTHREADS pieces is NTHREADS / 8 pixels, a multiple of 16, so the swizzle
+        // term ((Pl >> 1) & 7) of a lane does not depend on the round - one per-lane byte offset (computed once per tile),
+        // everything else scalar (r02: the 64-bit per-piece address arithmetic was ~10 % of this kernel's vector instructions)
+        for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
+            dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         xload(xf[0], xoff[0]);                                // step (t=0, mt=0): toff(0) = 0
@@ -514,7 +522,17 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
             xoff[mt] = qs[mt] - slab0 - (P + 1);
         }
     }
-    const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
+    // slab DMA by buffer addressing (see conv3x3s1_slab3_kernel): one per-lane byte offset, scalar offsets per line / round
+    static_assert((NTHREADS / 8) % 16 == 0, "whole swizzle periods per DMA round");
+    const size_t slab_byte0 = (size_t)slab0 * in_pixstride;
+    const size_t in_bytes = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * in_pixstride;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.in + slab_byte0), 0, (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000);
+    int xvoff;
+    {
+        const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+        xvoff = Pl * (int)in_pixstride + sl * 16;
+    }
     const char* wsrc = (const char*)a.wpk + (size_t)(nb * NTILES) * NC * 9 * 4096 + (size_t)(tid & 255) * 16;
     // weights of (line c, tap t) for the workgroup's NTILES channel tiles -> buffer wb: 256 pieces of 16 B per tile
     auto wdma = [&](int c, int t, char* wb) {
@@ -550,12 +568,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     int kpar = 0;                                             // weight buffer of the current tap
     for (int c = 0; c < NC; ++c) {
         if (c) __syncthreads();                               // slab and weight buffers are free again
-        for (int i0 = wave * 64; i0 < npieces; i0 += NTHREADS) {
-            const int i = i0 + lane;
-            const int Pl = i >> 3, sp = i & 7;
-            const int sl = sp ^ ((Pl >> 1) & 7);
-            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + sl * 16, xl + (size_t)i0 * 16);
-        }
+        for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
+            dma16_buf(xrs, xl + (size_t)i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
         wdma(c, 0, wl + kpar * WB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
