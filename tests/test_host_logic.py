@@ -236,3 +236,28 @@ def test_bag_logits_gather_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_fastdiv_magic_is_exact_for_31_bit_dividends():
+    """csrc/common.h FastDiv: q = mul_hi(i, m) >> s with m = floor(2^(31+l) / d) + 1, l = ceil(log2 d), must equal i // d for
+    every 0 <= i < 2^31 (the dense conv kernels decode pixel indices with it).  Checked on the boundary dividends of many
+    divisors, including every map size the kernels see."""
+    import random
+    rng = random.Random(5)
+    divisors = list(range(1, 2050)) + [65 * 65, 257 * 257, 4096, 65536, 12345, 999983, 2 ** 20 + 1, 2 ** 30, 2 ** 31 - 1] + \
+        [rng.randrange(2, 2 ** 31) for _ in range(300)]
+    top = 2 ** 31 - 1
+    for d in divisors:
+        if d <= 1:
+            continue
+        l = (d - 1).bit_length()
+        m = (1 << (31 + l)) // d + 1
+        assert m < 2 ** 32
+        s = l - 1
+        cands = {0, 1, d - 1, d, d + 1, top, top - 1, top // d * d, top // d * d - 1}
+        for k in (2, 3, 7, 1000, rng.randrange(1, max(2, top // d))):
+            cands.update({k * d - 1, k * d, k * d + 1})
+        cands.update(rng.randrange(0, top + 1) for _ in range(20))
+        for i in cands:
+            if 0 <= i <= top:
+                assert ((i * m) >> 32) >> s == i // d, (d, i)

@@ -359,8 +359,8 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
     ConvArgs a;
     a.in = in_pf; a.out = out_pf; a.resid = resid_pf; a.wpk = wpk; a.bias = bias;
-    a.gi = pf_geom(n, h_in, w_in, cin);
-    a.go = pf_geom(n, h_in / stride, w_in / stride, cout);
+    a.gi = pf_geom_fd(n, h_in, w_in, cin);
+    a.go = pf_geom_fd(n, h_in / stride, w_in / stride, cout);
     a.stride = stride; a.ksize = ksize; a.relu = relu & 1; a.flags = 0;
 #ifdef WSI_STUDY
     // study builds accept the r01 ablation masks of tools/tune_conv.py in `relu` (2 no stores, 64 dispatch only, 128 no main
@@ -425,8 +425,8 @@ static int s2_split_common(const void* in_split, void* out_conv_pf, void* out_ds
     if (in_split == out_conv_pf || in_split == out_ds_pf || out_conv_pf == out_ds_pf) return WSI_EINVAL;
     ConvArgs a;
     a.in = in_split; a.out = out_conv_pf; a.resid = nullptr; a.wpk = wpk3; a.bias = bias3;
-    a.gi = pf_geom(n, h_in, w_in, cin);
-    a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
+    a.gi = pf_geom_fd(n, h_in, w_in, cin);
+    a.go = pf_geom_fd(n, h_in / 2, w_in / 2, cout);
     a.stride = 2; a.ksize = 3; a.relu = 1; a.flags = 0;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
     a.out_split_pixels = 0;
@@ -448,8 +448,8 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
     if (in_pf == out_conv_pf || in_pf == out_ds_pf || out_conv_pf == out_ds_pf) return WSI_EINVAL;
     ConvArgs a;
     a.in = in_pf; a.out = out_conv_pf; a.resid = nullptr; a.wpk = wpk3; a.bias = bias3;
-    a.gi = pf_geom(n, h_in, w_in, cin);
-    a.go = pf_geom(n, h_in / 2, w_in / 2, cout);
+    a.gi = pf_geom_fd(n, h_in, w_in, cin);
+    a.go = pf_geom_fd(n, h_in / 2, w_in / 2, cout);
     a.stride = 2; a.ksize = 3; a.relu = 1; a.flags = 0;
     a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
     a.in_split_pixels = 0; a.out_split_pixels = 0;

@@ -28,17 +28,48 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define WSI_ENOMEM (-12)
 #define WSI_EFAULT (-14)
 
+// Division of a non-negative int below 2^31 by a launch constant: q = mul_hi(i, m) >> s, exact for every such i (m = floor(2^(31+l)
+// / d) + 1 with l = ceil(log2 d): the classic round-up magic, whose error d - (2^(31+l) mod d) <= 2^l keeps 31-bit dividends
+// exact); two instructions instead of the ~20 of a runtime division.  r02: the tile prologues of the dense conv kernels spent
+// 480-660 vector instructions per wave on `pixel index -> (n, y, x)`.
+struct FastDiv { unsigned m; int s; };
+static inline FastDiv fastdiv_make(int d) {
+    FastDiv f;
+    if (d <= 1) { f.m = 0u; f.s = -1; return f; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    f.m = (unsigned)(((1ull << (31 + l)) / (unsigned long long)d) + 1ull);
+    f.s = l - 1;
+    return f;
+}
+#ifdef __HIPCC__
+static inline __device__ int fd_div(int i, const FastDiv& f) { return f.s < 0 ? i : (int)(__umulhi((unsigned)i, f.m) >> f.s); }
+#endif
+
 struct PFGeom {          // padded-flat geometry of one activation tensor
     int N, H, W, C;
     int P, S, G;         // pitch, image stride, front guard (pixels)
     int NS;              // N*S
+    FastDiv dHW, dW, dS, dP;   // filled by pf_geom_fd on the host (kernels that use them take their geometry from the launcher)
 };
 
 static inline __host__ __device__ PFGeom pf_geom(int n, int h, int w, int c) {
     PFGeom g;
     g.N = n; g.H = h; g.W = w; g.C = c;
     g.P = w + 1; g.S = (h + 1) * (w + 1); g.G = w + 2; g.NS = n * g.S;
+    g.dHW.m = g.dW.m = g.dS.m = g.dP.m = 0u; g.dHW.s = g.dW.s = g.dS.s = g.dP.s = 0;
     return g;
+}
+static inline PFGeom pf_geom_fd(int n, int h, int w, int c) {          // host: geometry + the fast-division constants
+    PFGeom g = pf_geom(n, h, w, c);
+    g.dHW = fastdiv_make(h * w); g.dW = fastdiv_make(w); g.dS = fastdiv_make(g.S); g.dP = fastdiv_make(g.P);
+    return g;
+}
+// pixel index i (n, y, x raster order over real pixels) -> PF position
+static inline __device__ int pf_pos_of_index(const PFGeom& g, int i) {
+    const int n = fd_div(i, g.dHW), rem = i - n * (g.H * g.W);
+    const int y = fd_div(rem, g.dW), x = rem - y * g.W;
+    return g.G + n * g.S + y * g.P + x;
 }
 
 #define PF_TILE_ROUND 512        // M tiles never exceed this many pixels
@@ -117,9 +148,9 @@ enum : int {
 static inline __device__ size_t pf_out_offset(const PFGeom& g, long long split_pixels, int q, size_t pixstride) {
     if (!split_pixels) return (size_t)q * pixstride;
     int r = q - g.G;
-    const int n = r / g.S;
+    const int n = fd_div(r, g.dS);
     r -= n * g.S;
-    const int y = r / g.P, x = r - y * g.P;
+    const int y = fd_div(r, g.dP), x = r - y * g.P;
     const int P2 = g.W / 2 + 1, S2 = (g.H / 2 + 1) * P2;
     const long long q2 = (long long)(P2 + 1) + (long long)n * S2 + (y >> 1) * P2 + (x >> 1);
     return (size_t)(((y & 1) * 2 + (x & 1)) * split_pixels + q2) * pixstride;

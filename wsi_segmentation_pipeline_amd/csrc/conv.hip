@@ -142,11 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     int slab0, npieces;
     if constexpr (DENSE) {
         const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
-        auto pos = [&](int i) {
-            const int n = i / HW, rem = i - n * HW;
-            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
-            return a.gi.G + n * a.gi.S + y * P + x;
-        };
+        auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
         const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
         slab0 = pos(i0) - P - 1;
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
@@ -336,11 +332,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(Con
     const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
     const int nchunk = bufbytes / (NTHREADS * 16);
     const int cpt = (nchunk + 5) / 6;                         // DMA chunks per tap: all issued by tap 5
-    auto pos = [&](int i) {
-        const int n = i / HW, rem = i - n * HW;
-        const int y = rem / a.gi.W, x = rem - y * a.gi.W;
-        return a.gi.G + n * a.gi.S + y * P + x;
-    };
+    auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
     auto tile_slab = [&](int tile, int& slab0, int& npieces) {
         const int i0 = (tile / nblocks) * BM, i1 = min(i0 + BM, R) - 1;
         slab0 = pos(i0) - P - 1;
@@ -506,11 +498,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     int slab0, npieces;
     {
         const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
-        auto pos = [&](int i) {
-            const int n = i / HW, rem = i - n * HW;
-            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
-            return a.gi.G + n * a.gi.S + y * P + x;
-        };
+        auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
         const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
         slab0 = pos(i0) - P - 1;
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
@@ -652,11 +640,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_wide2_kernel(ConvArgs a) {
     int slab0, npieces;
     {
         const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
-        auto pos = [&](int i) {
-            const int n = i / HW, rem = i - n * HW;
-            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
-            return a.gi.G + n * a.gi.S + y * P + x;
-        };
+        auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
         const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
         slab0 = pos(i0) - P - 1;
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
@@ -1122,11 +1106,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         }
     } else {
         const int HW = a.go.H * a.go.W, R = a.go.N * HW;
-        auto pos = [&](int i) {
-            const int n = i / HW, rem = i - n * HW;
-            const int y = rem / a.go.W, x = rem - y * a.go.W;
-            return a.go.G + n * a.go.S + y * P + x;
-        };
+        auto pos = [&](int i) { return pf_pos_of_index(a.go, i); };
         const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
         q0 = pos(i0);
         qlast = pos(i1);

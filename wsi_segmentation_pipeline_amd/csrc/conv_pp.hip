@@ -69,11 +69,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
     const int lpix = l31 < 4 ? l31 : l31 < 12 ? l31 + 12 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 12 : l31;
     {
         const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
-        auto pos = [&](int i) {
-            const int n = i / HW, rem = i - n * HW;
-            const int y = rem / a.gi.W, x = rem - y * a.gi.W;
-            return a.gi.G + n * a.gi.S + y * P + x;
-        };
+        auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
         const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
         slab0 = pos(i0) - P - 1;
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
