@@ -223,7 +223,7 @@ int wsi_resample_tiles(const wsi_resample_plan* plan, const uint8_t* slide, long
  *                              scratch: wsi_connected_components_scratch_bytes.  Synchronises the stream (convergence flag).
  *   wsi_kmeans_points          utils/regiontools.py:89 key points: Lloyd iterations from the caller's initial centres on integer
  *                              (x, y) points, float64 distances, ties to the lower index, exact integer sums, empty clusters keep
- *                              their centre, stops when no label changes (the reference's sklearn KMeans is RNG / version
+ *                              their centre, stops when no label changes (the reference's sklearn MiniBatchKMeans is RNG / version
  *                              dependent: own deterministic spec); scratch: (3 k + 1) * 8 bytes.  Synchronises the stream. */
 int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, double mu_percent, uint8_t* mask_out, void* stream);
 size_t wsi_connected_components_scratch_bytes(int h, int w);

@@ -8,7 +8,7 @@ is absent and un-pinned here, so it is restated as a deterministic spec - **pari
       their first pixel (the published SAUF / BBDT labelling order).
   PIL Image.resize of label / mask images: NEAREST (dst pixel i <- src pixel floor((i + 0.5) * n_src / n_dst)); the
       reference relies on PIL's version-dependent default filter.
-  sklearn KMeans(n_clusters=k, random_state=0): version- and RNG-dependent; replaced by Lloyd's algorithm with a
+  sklearn MiniBatchKMeans (imported as KMeans; n_clusters=k, random_state=0): mini-batch sampling, version- and RNG-dependent; replaced by Lloyd's algorithm with a
       deterministic start (the points at ranks floor((2j + 1) N / (2k)) of the raster-ordered foreground list), squared
       Euclidean distances in float64, ties to the lower cluster index, integer coordinate sums, an empty cluster keeps its
       centre, at most 25 iterations (early exit when no assignment changes).

@@ -7,7 +7,7 @@ def get_key_points(image, us, min_clusters, max_clusters=None):
     """Centre points of a region by k-means on its downsampled foreground (reference :68-102; `max_clusters` is accepted and
     unused, as in the reference).  Runs on the HIP kernels of wsi_segmentation_pipeline_amd.proposals; `image` may be a GPU
     tensor or an ndarray (uploaded).  Returns (n, (k,2) int centre points, cluster image ndarray, foreground_indices) or 4 x None.
-    The clustering is the deterministic Lloyd spec of oracle/proposals_oracle.py, not sklearn's RNG-dependent k-means++."""
+    The clustering is the deterministic Lloyd spec of oracle/proposals_oracle.py, not sklearn's RNG-dependent mini-batch k-means."""
     import torch
     from wsi_segmentation_pipeline_amd import proposals as P
     if not torch.cuda.is_available():
