@@ -126,6 +126,59 @@ def test_two_rank_region_bags_equal_single_rank():
     assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
 
 
+# ------------------------------------------------------------------------------ dense 'seg' mode over two ranks
+def _seg(rank, world, out_dir):
+    import myargs
+    import utils.dataset as ds
+    import utils.eval as val
+    from wsi_segmentation_pipeline_amd import synthetic as W
+    from wsi_segmentation_pipeline_amd.slide import ArraySlide
+    from wsi_segmentation_pipeline_amd.unet import UNetSeg
+    a = myargs.args
+    a.scan_level, a.scan_resize, a.num_classes, a.class_probs = 2, 1, 4, [0., 0., 0., 0.]
+    a.tile_w = a.tile_h = 64
+    a.tile_stride_w = a.tile_stride_h = 48
+    a.val_save_pth, a.wsi_mask_pth = os.path.join(out_dir, 'out%d' % rank), os.path.join(out_dir, 'nomask')
+    rng = np.random.default_rng(13)
+    l2 = np.clip(np.kron(rng.integers(60, 250, (7, 9, 3)), np.ones((32, 32, 1))) + rng.integers(-25, 25, (224, 288, 3)), 0, 255).astype(np.uint8)
+    slide = ArraySlide([l2[:8, :8], l2[:8, :8], l2], [1.0, 4.0, 16.0])                       # only level 2 is read
+    slide.level_dimensions = ((288 * 16, 224 * 16), (288 * 4, 224 * 4), (288, 224))
+    slide.name = 'seg.svs'
+    model = UNetSeg(4)
+    model.load_state_dict(W.make_unet_state_dict(5, classes=4))
+    model = model.cuda().eval()
+    dataset = ds.Dataset_wsis({'seg.svs': slide}, {'ph': 64, 'pw': 64, 'sh': 48, 'sw': 48}, bs=5)
+    r = val.predict_tumorbed(model, dataset, 1, mode='seg', rank=rank, world=world, save=False)['seg.svs']
+    return {'heatmap': r['heatmap'], 'classes': r['classes']}
+
+
+def _seg_worker(rank, world, port, q, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    q.put((rank, _seg(rank, world, out_dir)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_seg_mode_equals_single_rank(tmp_path):
+    """predict_tumorbed(mode='seg') with the tile list cut over two ranks and ONE all-reduce of the float64 maps (SURVEY.md 8e,
+    seg mode) == the single-rank classes and heat map, byte for byte, on every rank."""
+    ref = _seg(0, 1, str(tmp_path))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for rank in (0, 1):
+        for k in ('heatmap', 'classes'):
+            assert np.array_equal(got[rank][k], ref[k]), (rank, k)
+
+
 @pytest.mark.parametrize('workload', ['cfg3', 'cfg4'])
 def test_rccl_path_rehearsal_single_rank(workload):
     """The 'nccl' (= RCCL) code path of bench.py - init_process_group with device_id, device all_gather_into_tensor,

@@ -113,21 +113,26 @@ class DeviceTileIterator:
     wsi_tile_gather kernel.  Order is raster order (the reference shuffles; results are
     order-independent, utils/eval.py accumulates sums)."""
 
-    def __init__(self, dataset, batch_size, device=None):
+    def __init__(self, dataset, batch_size, device=None, span=None):
         self.dataset, self.batch_size = dataset, int(batch_size)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self._lut = None
+        self.span = (0, len(dataset)) if span is None else (int(span[0]), int(span[1]))   # this rank's tiles [lo, hi)
 
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        return (self.span[1] - self.span[0] + self.batch_size - 1) // self.batch_size
+
+    def shard(self, lo, hi):
+        """The same producer restricted to tiles [lo, hi) of the raster-order list (one rank's share)."""
+        return DeviceTileIterator(self.dataset, self.batch_size, self.device, (lo, hi))
 
     def __iter__(self):
         ds = self.dataset
         level = ds.scan.device_level(args.scan_level, self.device)
         if self._lut is None:
             self._lut = torch.from_numpy(E.normalize_lut(args.dataset_mean, args.dataset_std)).to(self.device)
-        for i in range(0, len(ds), self.batch_size):
-            xy = ds.tile_xy[i:i + self.batch_size]
+        for i in range(self.span[0], self.span[1], self.batch_size):
+            xy = ds.tile_xy[i:min(i + self.batch_size, self.span[1])]
             if args.scan_resize != 1:
                 # reference :180-181: the (ph, pw) crop is PIL-resized to (tile_h, tile_w) before ToTensor + Normalize
                 from wsi_segmentation_pipeline_amd import ingest

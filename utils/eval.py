@@ -113,7 +113,14 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                 # int(m * y) over a (dy, dx) = int(m * ph), int(m * pw) footprint - which therefore has to equal the block size
                 pred = torch.zeros((args.num_classes,) + tuple(map_hw), dtype=torch.float64, device=dev)
                 dy, dx = int(m * ds.params.ph), int(m * ds.params.pw)
-                for batch_x, batch_y, batch_image in it:
+                # world > 1 (seg mode): every rank runs a contiguous share of the raster-order tile list into its
+                # own map, then ONE all-reduce (sum) of the float64 maps - exact, hence identical to the single-rank map, inside
+                # the exponent-span bound of the stitch
+                my_it = it
+                if world > 1:
+                    lo, hi = S.shard_range(len(ds), rank, world)
+                    my_it = it.shard(lo, hi)
+                for batch_x, batch_y, batch_image in my_it:
                     pred_src = model.decoder(model.encoder(batch_image.to(dev)))
                     if args.scan_resize != 1:
                         pred_src = E.resize_nearest(pred_src, (int(args.tile_h * args.scan_resize), int(args.tile_w * args.scan_resize)))
@@ -122,6 +129,8 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                                          "scan at the map's level or set scan_resize (utils/eval.py:202-215)" % (tuple(pred_src.shape[2:]), dy, dx))
                     xy = np.stack((batch_x.numpy(), batch_y.numpy()), 1)
                     E.stitch_add_dense(pred, pred_src, torch.from_numpy(S.map_coords(xy, m)))
+                if world > 1:
+                    pred = S.allreduce_map(pred)
                 classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'seg', want_probs=False)
                 r = {'logits': None, 'pred': pred, 'classes': classes, 'heatmap': heat}
             if r.get('exponent_span') is not None:             # the float64 stitch is exact (order-independent) inside this bound

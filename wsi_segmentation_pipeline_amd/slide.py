@@ -183,6 +183,19 @@ def gather_tile_logits(local_logits, total, rank, world):
     return torch.cat(parts, 0)
 
 
+def allreduce_map(pred):
+    """Sum a float64 prediction map over the ranks (dense 'seg' mode: each rank stitched its own tiles).  RCCL reduces device
+    buffers directly; gloo (CPU tests, or ranks sharing one GPU) goes through host memory.  Float64 sums of the fp32
+    addends are exact inside the stitch's exponent-span bound, so the result does not depend on the reduction order."""
+    import torch.distributed as dist
+    if dist.get_backend() == 'nccl' or not pred.is_cuda:
+        dist.all_reduce(pred, op=dist.ReduceOp.SUM)
+        return pred
+    host = pred.cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    return host.to(pred.device)
+
+
 # ------------------------------------------------------------------------------ rank-resident slide regions
 class SyntheticRows:
     """Position-deterministic i.i.d. uniform u8 RGB slide level: rows are generated on the
