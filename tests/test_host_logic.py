@@ -261,3 +261,41 @@ def test_fastdiv_magic_is_exact_for_31_bit_dividends():
         for i in cands:
             if 0 <= i <= top:
                 assert ((i * m) >> 32) >> s == i // d, (d, i)
+
+
+# ------------------------------------------------------------------------------ dense 'seg' mode: all-reduce of the float64 maps
+def _allreduce_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(3)
+    tiles = torch.randn(40, 4, 8, 8, generator=g)                                   # fp32 addends, as the decoder produces them
+    xy = torch.randint(0, 24, (40, 2), generator=g)
+    lo, hi = S.shard_range(40, rank, world)
+    pred = torch.zeros(4, 32, 32, dtype=torch.float64)
+    for t in range(lo, hi):
+        x, y = int(xy[t, 0]), int(xy[t, 1])
+        pred[:, y:y + 8, x:x + 8] += tiles[t].double()
+    out = S.allreduce_map(pred)
+    ref = torch.zeros(4, 32, 32, dtype=torch.float64)
+    for t in torch.randperm(40, generator=g).tolist():                              # any order: the sums are exact
+        x, y = int(xy[t, 0]), int(xy[t, 1])
+        ref[:, y:y + 8, x:x + 8] += tiles[t].double()
+    q.put((rank, bool(torch.equal(out, ref))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_map_gloo_world2():
+    """slide.allreduce_map (the seg-mode exchange): per-rank float64 maps of disjoint tile shares sum to the single-rank map bit
+    for bit, whatever the accumulation order."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
