@@ -73,17 +73,6 @@ static void bn_fold(const float* g, const float* b, const float* m, const float*
     scale = (double)g[co] / sqrt((double)v[co] + (double)eps);
     shift = (double)b[co] - (double)m[co] * scale;
 }
-// nearest fp4 (e2m1) code of y (round-to-nearest-even on the 1-bit mantissa, saturating), like v_cvt_scalef32_pk_fp4_f32
-static inline unsigned fp4_encode(float y) {
-    const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
-    const float a = fabsf(y);
-    int best = 7;
-    for (int i = 0; i < 7; ++i) {
-        const float mid = 0.5f * (mag[i] + mag[i + 1]);
-        if (a < mid || (a == mid && (i & 1) == 0)) { best = i; break; }
-    }
-    return (unsigned)best | ((y < 0.f || (y == 0.f && signbit(y))) ? 8u : 0u);
-}
 static inline float f16_round(float x) { return (float)(_Float16)x; }
 static inline uint16_t f16_bits(float x) {
     const _Float16 hf = (_Float16)x;
@@ -144,9 +133,11 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
         bias_out[co] = (float)sh;
     }
     if (planes == 3) {
-        // per (cout, line, tap): fp16 hi of the 32 channels; hi4 / lo4 = MX-fp4 of hi / (w - hi) with one E8M0
-        // scale per block.  frag 0/1: fp16 k-steps; frag 2: lanes h=0 carry Wh4, h=1 carry Wl4 (the two K halves
-        // of the MX instruction pair with Xl4 / Xh4); frag 3: dword 0 = that lane's block scale byte.
+        // per (cout, line, tap): fp16 hi of the 32 channels; hi6 / lo6 = MX-fp6 (e2m3) of hi / (w - hi) with one E8M0
+        // scale per block.  frag 0/1: fp16 k-steps (K position = activation line position, common.h mx_line_chan);
+        // frag 2: dwords 0-3 of the lane's fp6 plane - lanes h=0 carry Wh6, h=1 carry Wl6 (the two K halves of the MX
+        // instruction pair with Xl6 / Xh6), K position = activation field order (mx6_field_chan); frag 3: {dwords 4-5 of
+        // the plane, the plane's block scale byte, 0}.
         memset(wpk_out, 0, wsi_prepack_conv_bytes(cout, cin, k, planes));
         for (int nt = 0; nt < cout / 32; ++nt)
             for (int l = 0; l < NL; ++l)
@@ -156,31 +147,35 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
                         const int co = nt * 32 + r;
                         double sc, sh;
                         bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
-                        float hi[32], lo[32], mh = 0.f, ml = 0.f;
+                        float hi[32], lo[32], mh = 0.f, ml = 0.f;                     // indexed by CHANNEL inside the line
                         for (int ci = 0; ci < 32; ++ci) {
-                            // ci = K position inside the line; its channel follows the activation line order
-                            const float wf = (float)((double)w[(((size_t)co * cin + 32 * l + mx_line_chan(ci)) * k + t / k) * k + t % k] * sc);
+                            const float wf = (float)((double)w[(((size_t)co * cin + 32 * l + ci) * k + t / k) * k + t % k] * sc);
                             hi[ci] = f16_round(wf);
                             lo[ci] = wf - hi[ci];
                             mh = fmaxf(mh, fabsf(hi[ci]));
                             ml = fmaxf(ml, fabsf(lo[ci]));
                         }
-                        const int sh_b = mx4_scale_byte(mh), sl_b = mx4_scale_byte(ml);
-                        const float ih = sh_b ? 1.0f / mx4_scale_value(sh_b) : 0.f, il = sl_b ? 1.0f / mx4_scale_value(sl_b) : 0.f;
+                        const int sh_b = mx6_scale_byte(mh), sl_b = mx6_scale_byte(ml);
+                        const float ih = sh_b ? 1.0f / mx_scale_value(sh_b) : 0.f, il = sl_b ? 1.0f / mx_scale_value(sl_b) : 0.f;
                         for (int h = 0; h < 2; ++h) {
                             const int lane = r + 32 * h;
                             uint16_t* f0 = (uint16_t*)(base + 0 * 1024 + lane * 16);
                             uint16_t* f1 = (uint16_t*)(base + 1 * 1024 + lane * 16);
                             for (int j = 0; j < 8; ++j) {
-                                f0[j] = f16_bits(hi[8 * h + j]);
-                                f1[j] = f16_bits(hi[16 + 8 * h + j]);
+                                f0[j] = f16_bits(hi[mx_line_chan(8 * h + j)]);
+                                f1[j] = f16_bits(hi[mx_line_chan(16 + 8 * h + j)]);
                             }
-                            uint8_t* f2 = base + 2 * 1024 + lane * 16;
-                            for (int ci = 0; ci < 32; ++ci) {
-                                const unsigned q = h == 0 ? fp4_encode(hi[ci] * ih) : fp4_encode(lo[ci] * il);
-                                f2[ci >> 1] |= (uint8_t)(q << (4 * (ci & 1)));
+                            unsigned pl[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+                            for (int f = 0; f < 32; ++f) {
+                                const int ci = mx6_field_chan(f);
+                                mx6_set_field(pl, f, h == 0 ? fp6_encode(hi[ci] * ih) : fp6_encode(lo[ci] * il));
                             }
-                            *(uint32_t*)(base + 3 * 1024 + lane * 16) = (uint32_t)(h == 0 ? sh_b : sl_b);
+                            uint32_t* f2 = (uint32_t*)(base + 2 * 1024 + lane * 16);
+                            uint32_t* f3 = (uint32_t*)(base + 3 * 1024 + lane * 16);
+                            for (int d = 0; d < 4; ++d) f2[d] = pl[d];
+                            f3[0] = pl[4];
+                            f3[1] = pl[5];
+                            f3[2] = (uint32_t)(h == 0 ? sh_b : sl_b);
                         }
                     }
                 }

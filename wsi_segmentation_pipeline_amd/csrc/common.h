@@ -92,10 +92,13 @@ static inline __device__ bool pf_is_pixel(const PFGeom& g, int q) {
 // Precision / storage modes ("planes" in the C ABI):
 //   1  bf16 single             line = 64 channels x 2 B                              (speed mode)
 //   2  bf16 hi + bf16 lo       line = 32 channels: [hi x32][lo x32]                  (3 MFMA passes)
-//   3  fp16 hi + MX-fp4 cross  line = 32 channels: [hi fp16 x32 | lo4 16 B | hi4 16 B | scale_lo dword.. | scale_hi dword..]
-//      x = hi + lo4*2^(scale_lo-127); the conv is  Wh*Xh (two fp16 MFMAs)  +  [Wh4*Xl4 | Wl4*Xh4] as the two
-//      K halves of ONE v_mfma_scale_f32_32x32x64_f8f6f4 (block scale per 32 channels): 3 instructions per
-//      (tile, line, tap) instead of 6 (tools/sim_mx_numerics.py, tools/probes/mx_*.hip)
+//   3  fp16 hi + MX-fp6 cross  line = 32 channels: [hi fp16 x32 (64 B) | lo6 fields 0-20 (16 B) | hi6 fields 0-20 (16 B) |
+//                              lo6 rest (8 B) scale_lo (4 B) pad | hi6 rest (8 B) scale_hi (4 B) pad]
+//      x = hi + lo6*2^(scale_lo-127); the conv is  Wh*Xh (two fp16 MFMAs)  +  [Wh6*Xl6 | Wl6*Xh6] as the two K halves of ONE
+//      v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 (e2m3) operands, one E8M0 block scale per 32 channels: 3 instructions per
+//      (tile, line, tap) instead of the 6 of mode 2.  r01-r02 shipped fp4 (e2m1) cross terms in the same 128 bytes; fp6 runs
+//      at the same MFMA rate (tools/probes/mx_rate.hip) with 5x finer operands (tests/studies/sim_mx_margin.py,
+//      tools/probes/mx6_layout.hip)
 template <int PLANES> struct PFmt {
     static constexpr int BPC = PLANES == 1 ? 2 : 4;          // bytes per channel in a pixel record
     static constexpr int CPL = PLANES == 1 ? 64 : 32;        // channels per 128-byte line
@@ -105,6 +108,7 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 struct ConvArgs {
@@ -161,49 +165,125 @@ static inline __device__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // mode 3 helpers ---------------------------------------------------------------------------
-// E8M0 exponent byte s such that amax / 2^(s-127) <= 6 (fp4 e2m1 max); amax == 0 -> 0
-static inline __host__ __device__ int mx4_scale_byte(float amax) {
-    if (!(amax > 0.f)) return 0;
-    const float t = amax * (1.0f / 6.0f);
+typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
+typedef __attribute__((ext_vector_type(32))) float f32x32;
+// E8M0 exponent byte s of a block with largest magnitude amax: the smallest s with amax / 2^(s-127) <= 7.75, i.e. the
+// largest element lands in fp6's top binade [4, 7.5] (values in (7.5, 7.75] saturate to 7.5: an error below the top
+// binade's own rounding error of 0.25).  Integer arithmetic on the float's bits: amax = m * 2^e with m in [1, 2), and
+// 7.75 = 1.9375 * 2^2, so s - 127 = e - 2 (+ 1 if m > 1.9375).  amax == 0 -> 0 (the block decodes to zeros).
+static inline __host__ __device__ int mx6_scale_byte(float amax) {
     union { float f; unsigned u; } c;
-    c.f = t;
-    int e = (int)((c.u >> 23) & 255) + ((c.u & 0x7fffffu) ? 1 : 0);   // ceil(log2 t) + 127
+    c.f = amax;
+    const unsigned u = c.u & 0x7fffffffu;
+    if (u == 0u) return 0;
+    const int e = (int)(u >> 23) - 2 + ((u & 0x7fffffu) > 0x780000u ? 1 : 0);
     return e < 1 ? 1 : (e > 254 ? 254 : e);
 }
-static inline __host__ __device__ float mx4_scale_value(int s) {
+static inline __host__ __device__ float mx_scale_value(int s) {
     union { float f; unsigned u; } c;
     c.u = (unsigned)s << 23;                                  // 2^(s-127), s in [1,254]
     return c.f;
 }
 // Mode-3 channel order inside a 32-channel line.  The 32x32 MFMA accumulator leaves lane (pixel, h) with the
-// 16 couts 8g + 4h + i (register r = 4g + i): storing them at line positions 16h + r makes every lane's share of
-// the line contiguous (32 B of fp16, 8 B of each fp4 plane), so the epilogue and the residual read move 16-byte
-// pieces.  K order inside a line is free as long as weights and pixels agree: prepack uses the same map.
+// 16 couts 8g + 4h + i (register r = 4g + i).  fp16 plane: line position 16h + r, so every lane's share is 32
+// contiguous bytes and the epilogue moves 16-byte pieces.  fp6 planes: field 2r + h - what
+// v_cvt_scalef32_2xpk16_fp6_f32 produces from (values of the h=0 lane, values of the h=1 lane), which interleaves its
+// two sources.  K order inside a line is free as long as weights and pixels agree: prepack uses the same maps.
 static inline __host__ __device__ int mx_line_pos(int c) { return 16 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3); }
 static inline __host__ __device__ int mx_line_chan(int p) { return 8 * ((p & 15) >> 2) + 4 * (p >> 4) + (p & 3); }
+static inline __host__ __device__ int mx6_field_of_pos(int p) { return 2 * (p & 15) + (p >> 4); }      // fp16 position -> fp6 field
+static inline __host__ __device__ int mx6_field_chan(int f) { return mx_line_chan(16 * (f & 1) + (f >> 1)); }
+// byte offsets inside a 128-byte line: plane q (0 = lo6, 1 = hi6) keeps fields 0..20 (+ 2 bits of 21) in slot 4 + q and
+// its last 64 bits in slot 6 + q, followed by the plane's scale dword
+#define MX6_PLANE_LO(q) (64 + 16 * (q))
+#define MX6_PLANE_HI(q) (96 + 16 * (q))
+#define MX6_SCALE(q) (104 + 16 * (q))
 
-// 8 floats -> one dword of fp4 (RNE(v / scale), saturating); the byte selector must be a literal
-static __device__ __forceinline__ unsigned mx4_pack8(const float* v, float scale) {
-    unsigned q = 0u;
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[0], v[1], scale, 0);
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[2], v[3], scale, 1);
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[4], v[5], scale, 2);
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[6], v[7], scale, 3);
-    return q;
+// fp6 (e2m3) value of a 6-bit code / nearest code of y (round-to-nearest-even, saturating at 7.5: the rule of
+// v_cvt_scalef32_2xpk16_fp6_f32, tools/probes/mx6_layout.hip)
+static inline __host__ __device__ float fp6_value(unsigned c) {
+    const int e = (c >> 3) & 3, m = c & 7;
+    const float v = e ? (float)(8 + m) * (e == 1 ? 0.125f : e == 2 ? 0.25f : 0.5f) : (float)m * 0.125f;
+    return (c & 32) ? -v : v;
 }
-// one dword of fp4 -> 8 floats (value * scale)
-static __device__ __forceinline__ void mx4_unpack8(unsigned q, float scale, float* v) {
-    const f32x2 a = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 0), b = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 1);
-    const f32x2 c = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 2), d = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, scale, 3);
-    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1]; v[6] = d[0]; v[7] = d[1];
+static inline __host__ __device__ unsigned fp6_encode(float y) {
+    union { float f; unsigned u; } c;
+    c.f = y;
+    const unsigned sign = (c.u >> 31) ? 32u : 0u;
+    c.u &= 0x7fffffffu;
+    const float a = c.f;
+    if (!(a < 7.5f)) return sign | 31u;                       // saturate (also NaN)
+    // step of the grid at a: 0.125 below 2, 0.25 in [2, 4), 0.5 in [4, 7.5]
+    const float step = a < 2.f ? 0.125f : a < 4.f ? 0.25f : 0.5f;
+    const float t = a / step;                                 // exact (power-of-two step)
+    float r = (float)(int)t;
+    const float frac = t - r;
+    if (frac > 0.5f || (frac == 0.5f && ((int)r & 1))) r += 1.f;
+    const float q = r * step;                                 // on the grid, possibly the first value of the next binade
+    unsigned code;
+    if (q < 1.f) code = (unsigned)(q * 8.f);                  // subnormals m / 8
+    else if (q < 2.f) code = 8u + (unsigned)((q - 1.f) * 8.f);
+    else if (q < 4.f) code = 16u + (unsigned)((q - 2.f) * 4.f);
+    else code = 24u + (unsigned)((q - 4.f) * 2.f);
+    return sign | code;
+}
+// 6-bit field f of a plane stored as six little-endian dwords
+static inline __host__ __device__ unsigned mx6_get_field(const unsigned* w, int f) {
+    const int bit = 6 * f, d = bit >> 5, s = bit & 31;
+    unsigned v = w[d] >> s;
+    if (s > 26) v |= w[d + 1] << (32 - s);
+    return v & 63u;
+}
+static inline __host__ __device__ void mx6_set_field(unsigned* w, int f, unsigned code) {
+    const int bit = 6 * f, d = bit >> 5, s = bit & 31;
+    w[d] |= code << s;
+    if (s > 26) w[d + 1] |= code >> (32 - s);
 }
 
-// decode one fp4 (e2m1) nibble
-static inline __host__ __device__ float fp4_value(unsigned n) {
-    const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
-    const float v = mag[n & 7];
-    return (n & 8) ? -v : v;
+#ifdef __HIPCC__
+// 2 x 16 floats -> 32 fp6 fields (RNE(v / scale), saturating): field 2i = a[i], field 2i + 1 = b[i].  Inline asm with an
+// early-clobber result: hipcc (ROCm 7.2) lets the builtin's 6-register result overlap the tail of its second source,
+// which the instruction has not finished reading when it writes (tools/probes/mx6_layout.hip: the last two fields of b
+// came out wrong).
+static __device__ __forceinline__ u32x6 mx6_pack32(f32x16 a, f32x16 b, float scale) {
+    u32x6 r;
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
+    return r;
 }
+// 32 fp6 fields -> 32 floats (field * scale), same early-clobber caution
+static __device__ __forceinline__ f32x32 mx6_unpack32(u32x6 q, float scale) {
+    f32x32 r;
+    asm volatile("v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2" : "=&v"(r) : "v"(q), "v"(scale));
+    return r;
+}
+// Exchange between the two lanes of a pixel (l, l ^ 32): lanes 32-63 of a[i] <-> lanes 0-31 of b[i].  After it a lane of
+// the lower half holds (its own a, the partner's a), a lane of the upper half (the partner's b, its own b).
+// v_permlane32_swap_b32 by inline asm: at -O1 and above hipcc (ROCm 7.2) folds BOTH results of
+// __builtin_amdgcn_permlane32_swap into the first.  The leading s_nop covers the two wait states between a VALU write
+// of an operand and the swap (hipcc pads nothing inside asm).
+static __device__ __forceinline__ void swap32_halves(f32x16& a, f32x16& b) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 8) {
+        float a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3], a4 = a[k + 4], a5 = a[k + 5], a6 = a[k + 6], a7 = a[k + 7];
+        float b0 = b[k], b1 = b[k + 1], b2 = b[k + 2], b3 = b[k + 3], b4 = b[k + 4], b5 = b[k + 5], b6 = b[k + 6], b7 = b[k + 7];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
+                     "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+                     "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\ts_nop 1"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                       "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+        a[k] = a0; a[k + 1] = a1; a[k + 2] = a2; a[k + 3] = a3; a[k + 4] = a4; a[k + 5] = a5; a[k + 6] = a6; a[k + 7] = a7;
+        b[k] = b0; b[k + 1] = b1; b[k + 2] = b2; b[k + 3] = b3; b[k + 4] = b4; b[k + 5] = b5; b[k + 6] = b6; b[k + 7] = b7;
+    }
+}
+// max over the two lanes of a pixel (l, l ^ 32) of two values at once, by one v_permlane32_swap each (see swap32_halves)
+static __device__ __forceinline__ void pair_max2(float& x, float& y) {
+    float x2 = x, y2 = y;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(x), "+v"(x2), "+v"(y), "+v"(y2));
+    x = fmaxf(x, x2);
+    y = fmaxf(y, y2);
+}
+
+#endif
 
 // fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative
 static inline __device__ void split_bf16(float x, __bf16& hi, __bf16& lo) {

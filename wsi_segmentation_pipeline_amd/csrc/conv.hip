@@ -108,6 +108,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
     constexpr int NTHREADS = WM * WN * 64;
+    constexpr int RESID_NBUF = MT < 2 ? MT : 2;               // residual tiles per batch and wave (mode 3; launch_slab3 sizes the LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     if (CONV_STUDY(a, CONV_ABL_DISPATCH_ONLY)) return;         // study builds: dispatch cost only
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,11 +182,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         (void*)((const char*)a.wpk + wcopy + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
     const int wvoff = lane * 16;
 
-    f32x16 acc[MT];
+    f32x16 acc[1][MT];                                        // [1]: the shape conv_residual_mx takes
+    if constexpr (PLANES == 3) acc_init_bias<MT>(acc[0], a.bias, ntile, lane);
+    else {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[0][mt][r] = 0.f;
+    }
     auto wload = [&](bf16x8(&w)[4], int soff) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -194,8 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     auto xload = [&](bf16x8(&x)[4], int Pl) {
         const int base = lds_xbase(Pl, h);
 #pragma unroll
-        for (int f = 0; f < (PLANES == 3 ? 3 : 4); ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
-        if constexpr (PLANES == 3) x[3] = lds_xscale(smem, base, Pl);
+        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
     };
 
     for (int c = 0; c < NC; ++c) {
@@ -232,35 +235,34 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
                 const bf16x8(&x)[4] = xf[k & 1];
                 if constexpr (ABL & 8) {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[mt][f] += (float)w[f][0] * (float)x[f][0];   // keeps the loads alive
+                    for (int f = 0; f < 4; ++f) acc[0][mt][f] += (float)w[f][0] * (float)x[f][0];   // keeps the loads alive
                 } else if constexpr (PLANES == 3) {
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), acc[mt], 0, 0, 0);
-                    const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-                    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-                    acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, acc[mt], 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                                              __builtin_bit_cast(i32x4, x[3])[0]);
+                    acc[0][mt] = mfma_mx6(acc[0][mt], w, x);
                 } else if constexpr (PLANES == 2) {
-                    acc[mt] = mfma_bf16(w[2], x[0], acc[mt]);   // lo*hi
-                    acc[mt] = mfma_bf16(w[3], x[1], acc[mt]);
-                    acc[mt] = mfma_bf16(w[0], x[2], acc[mt]);   // hi*lo
-                    acc[mt] = mfma_bf16(w[1], x[3], acc[mt]);
-                    acc[mt] = mfma_bf16(w[0], x[0], acc[mt]);   // hi*hi
-                    acc[mt] = mfma_bf16(w[1], x[1], acc[mt]);
+                    acc[0][mt] = mfma_bf16(w[2], x[0], acc[0][mt]);   // lo*hi
+                    acc[0][mt] = mfma_bf16(w[3], x[1], acc[0][mt]);
+                    acc[0][mt] = mfma_bf16(w[0], x[2], acc[0][mt]);   // hi*lo
+                    acc[0][mt] = mfma_bf16(w[1], x[3], acc[0][mt]);
+                    acc[0][mt] = mfma_bf16(w[0], x[0], acc[0][mt]);   // hi*hi
+                    acc[0][mt] = mfma_bf16(w[1], x[1], acc[0][mt]);
                 } else {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(w[f], x[f], acc[mt]);
+                    for (int f = 0; f < 4; ++f) acc[0][mt] = mfma_bf16(w[f], x[f], acc[0][mt]);
                 }
             }
         }
     }
-    char* scratch = nullptr;
-    if (PLANES >= 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {        // slab memory becomes the waves' residual staging (bit 65536: A/B off)
-        __syncthreads();                                      // every wave is done reading pixel fragments
-        scratch = smem + wave * 8192;
+    if constexpr (PLANES == 3) {
+        if (a.resid) __syncthreads();                         // every wave is done reading pixel fragments: slab memory becomes
+        conv_tail_mx<1, MT, RESID_NBUF>(a, acc, qs, valid, ntile, lane, smem + wave * (RESID_NBUF * 4096));   // the waves' residual staging
+    } else {
+        char* scratch = nullptr;
+        if (PLANES == 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {
+            __syncthreads();
+            scratch = smem + wave * 8192;
+        }
+        conv_epilogue_q<MT, PLANES>(a, acc[0], qs, valid, ntile, lane, scratch);
     }
-    if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane, scratch);
-    else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane, scratch);
 }
 
 // exact largest slab (pixels) over the dense tiles of BM real pixels
@@ -306,159 +308,6 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-#ifdef WSI_STUDY   // measured-negative result kept for studies (r01: 5-25 % slower than slab3)
-// --------------------------------------------------------------------------------------------
-// Streamed form of the dense slab kernel: a PERSISTENT workgroup walks tiles blockIdx.x, +gridDim.x, ...
-// and treats (tile, 128-byte line) pairs as one stream of work items.  Two slab buffers: while item i
-// is multiplied out of buffer i&1, the slab of item i+1 (the next line, or line 0 of the NEXT tile) is
-// fetched by LDS-DMA into the other buffer, in chunks issued after each tap's weight prefetch (VMEM
-// completes in order: a chunk issued behind the weights of tap t+1 is only waited for by tap t+2's
-// weights, so it has two taps of MFMA time, plus the other resident waves, to land).  The epilogue of
-// a tile runs while the first slab of the next tile is already in flight.  One barrier per item.
-template <int MT, int WM, int WN, int PLANES, int MINW>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_stream_kernel(ConvArgs a, int mtiles, int bufbytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = WM * MT * 32;
-    constexpr int NTHREADS = WM * WN * 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nblocks = a.go.C / (WN * 32);
-    const int total = mtiles * nblocks;
-    const int P = a.gi.P;
-    const int NC = a.gi.C / PFmt<PLANES>::CPL;
-    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
-    const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
-    const int nchunk = bufbytes / (NTHREADS * 16);
-    const int cpt = (nchunk + 5) / 6;                         // DMA chunks per tap: all issued by tap 5
-    auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
-    auto tile_slab = [&](int tile, int& slab0, int& npieces) {
-        const int i0 = (tile / nblocks) * BM, i1 = min(i0 + BM, R) - 1;
-        slab0 = pos(i0) - P - 1;
-        npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
-    };
-    const __amdgpu_buffer_rsrc_t wrs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (a.go.C / 32) * NC * 9 * 4096, 0x00020000);
-    const int wvoff = lane * 16;
-    auto wload = [&](bf16x8(&w)[4], int soff) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-            w[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + f * 1024, soff, 0));
-    };
-    // chunk j of a slab: 16-byte piece i = j*NTHREADS + tid, source swizzled so LDS piece i holds slot (i&7)^((Pl>>1)&7)
-    auto dma_chunk = [&](int j, const char* src, char* dst, int npieces) {
-        const int i0 = wave * 64 + j * NTHREADS;
-        if (i0 < npieces) {
-            const int i = i0 + lane;
-            const int Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
-            dma16(src + (size_t)Pl * in_pixstride + sl * 16, dst + (size_t)i0 * 16);
-        }
-    };
-
-    int tile = blockIdx.x;                                    // host launches gridDim.x <= total
-    int slab0, npieces;
-    tile_slab(tile, slab0, npieces);
-    for (int j = 0; j < nchunk; ++j) dma_chunk(j, (const char*)a.in + (size_t)slab0 * in_pixstride, smem, npieces);
-    bf16x8 wbuf[3][4], xf[2][4];
-    int item = 0;
-    {
-        const int ntile0 = (tile % nblocks) * WN + wn;
-        wload(wbuf[0], ntile0 * NC * 9 * 4096);
-    }
-    for (;;) {
-        const int ntile = (tile % nblocks) * WN + wn;
-        int xoff[MT], qs[MT];
-        bool valid[MT];
-        {
-            const int i0 = (tile / nblocks) * BM, i1 = min(i0 + BM, R) - 1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int i = i0 + wm * MT * 32 + mt * 32 + l31;
-                valid[mt] = i < R;
-                qs[mt] = pos(valid[mt] ? i : i1);
-                xoff[mt] = qs[mt] - slab0 - (P + 1);
-            }
-        }
-        const int tn = tile + gridDim.x;
-        const bool more = tn < total;
-        int slab0_n = 0, npieces_n = 0;
-        if (more) tile_slab(tn, slab0_n, npieces_n);
-        const int wnext_tile = more ? ((tn % nblocks) * WN + wn) * NC * 9 * 4096 : 0;
-
-        f32x16 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-        for (int c = 0; c < NC; ++c, ++item) {
-            const char* sb = smem + (size_t)(item & 1) * bufbytes;
-            char* nbuf = smem + (size_t)((item + 1) & 1) * bufbytes;
-            const bool lastc = c == NC - 1;
-            const char* nsrc = (const char*)a.in + (size_t)(lastc ? slab0_n : slab0) * in_pixstride + (lastc ? 0 : (c + 1) * 128);
-            const int np_next = lastc ? (more ? npieces_n : 0) : npieces;
-            const int wline = (ntile * NC + c) * 9 * 4096;
-            const int wnext = lastc ? wnext_tile : wline + 9 * 4096;
-            int Pc = P;                                       // opaque per item (see slab3 kernel)
-            asm volatile("" : "+s"(Pc));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this item's slab (and tap-0 weights) have landed
-            __syncthreads();                                  // ...for every wave; the other buffer is free again
-            auto xload = [&](bf16x8(&x)[4], int Pl) {
-                const int base = lds_xbase(Pl, h);
-#pragma unroll
-                for (int f = 0; f < (PLANES == 3 ? 3 : 4); ++f) x[f] = *(const bf16x8*)(sb + (base ^ (f << 5)));
-                if constexpr (PLANES == 3) x[3] = lds_xscale(sb, base, Pl);
-            };
-            xload(xf[0], xoff[0]);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                asm volatile("" ::: "memory");
-                if (t < 8) wload(wbuf[(t + 1) % 3], wline + (t + 1) * 4096);
-                else if (np_next) wload(wbuf[0], wnext);      // tap 0 of the next item
-                if (t < 6)
-                    for (int jj = 0; jj < cpt; ++jj) dma_chunk(t * cpt + jj, nsrc, nbuf, np_next);
-                asm volatile("" ::: "memory");
-                const int toff = (t / 3) * Pc + (t % 3);
-                const int toff_next = ((t + 1) / 3) * Pc + ((t + 1) % 3);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int k = t * MT + mt;
-                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
-                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
-                    const bf16x8(&w)[4] = wbuf[t % 3];
-                    const bf16x8(&x)[4] = xf[k & 1];
-                    if constexpr (PLANES == 3) {
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), acc[mt], 0, 0, 0);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), acc[mt], 0, 0, 0);
-                        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-                        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-                        acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, acc[mt], 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                                                  __builtin_bit_cast(i32x4, x[3])[0]);
-                    } else if constexpr (PLANES == 2) {
-                        acc[mt] = mfma_bf16(w[2], x[0], acc[mt]);
-                        acc[mt] = mfma_bf16(w[3], x[1], acc[mt]);
-                        acc[mt] = mfma_bf16(w[0], x[2], acc[mt]);
-                        acc[mt] = mfma_bf16(w[1], x[3], acc[mt]);
-                        acc[mt] = mfma_bf16(w[0], x[0], acc[mt]);
-                        acc[mt] = mfma_bf16(w[1], x[1], acc[mt]);
-                    } else {
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(w[f], x[f], acc[mt]);
-                    }
-                }
-            }
-        }
-        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
-        else conv_epilogue_q<MT, PLANES>(a, acc, qs, valid, ntile, lane);
-        if (!more) break;
-        tile = tn;
-        slab0 = slab0_n;
-        npieces = npieces_n;
-    }
-}
-
-#endif  // WSI_STUDY
 
 // --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
@@ -475,7 +324,7 @@ template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 4, BM = WM * 128, NTHREADS = WM * WN * 64, NTILES = WN * NT, WB = NTILES * 4096;
-    constexpr int NF = PLANES == 3 ? 3 : 4;                   // 16-byte fragments per operand set (+ scale dword in mode 3)
+    constexpr int RESID_NBUF = 4;                             // residual tiles in flight per wave (mode 3; launch_wide sizes the LDS)
     char* const wl = smem;                                    // 2 weight buffers of NTILES x 4 KB
     char* const xl = smem + 2 * WB;                           // pixel slab
     const int tid = threadIdx.x, lane = tid & 63;
@@ -534,23 +383,25 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
 
     f32x16 acc[NT][MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (PLANES == 3) acc_init_bias<MT>(acc[nt], a.bias, nb * NTILES + wn * NT + nt, lane);
+        else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+        }
+    }
 
     auto xload = [&](bf16x8(&x)[4], int Pl) {
         const int base = lds_xbase(Pl, h);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
-        if constexpr (PLANES == 3) x[3] = lds_xscale(xl, base, Pl);
+        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
     };
     auto wread = [&](bf16x8(&w)[4], const char* wb, int nt) {
         const char* src = wb + (wn * NT + nt) * 4096 + lane * 16;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) w[f] = *(const bf16x8*)(src + f * 1024);
-        if constexpr (PLANES == 3) w[3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + 3 * 1024), 0u, 0u, 0u});
+        for (int f = 0; f < 4; ++f) w[f] = *(const bf16x8*)(src + f * 1024);
     };
 
     int kpar = 0;                                             // weight buffer of the current tap
@@ -594,219 +445,20 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
             kpar ^= 1;
         }
     }
-    char* scratch = nullptr;
-    if (PLANES >= 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {        // slab memory becomes the waves' residual staging (epilogues)
-        __syncthreads();
-        scratch = xl + wave * 8192;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = nb * NTILES + wn * NT + nt;
-        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane, scratch);
-        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane, scratch);
-    }
-}
-
-#ifdef WSI_STUDY   // measured-negative result kept for studies (r01: 5-10 % slower than the wide kernel)
-// --------------------------------------------------------------------------------------------
-// "Wide", fully asynchronous form: ONE workgroup per CU (one wave per SIMD, up to 512 registers each), every
-// global byte arrives by LDS-DMA and is double- (slab) or quadruple- (weights) buffered, so no MFMA ever waits on
-// HBM or L2: the slab of line c+1 is requested at the start of line c and only waited for at its end (a whole line
-// of MFMA time to land); the weights of tap g+3 are requested during tap g.  vmcnt completes in order per wave, so
-// the two kinds of DMA are issued by DIFFERENT waves (waves 0-1: slabs, waves 2-3: weights): the per-tap counted
-// wait of the weight waves never waits for a slab.  Weight fragments for tap g+1 are read from LDS into a second
-// register set while tap g multiplies.  One barrier per tap.
-template <int PLANES, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv3x3s1_wide2_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, NT = 2, BM = 256;
-    constexpr int NF = PLANES == 3 ? 3 : 4;
-    constexpr int WBUF = 16384, NWB = 4;
-    constexpr int XB = 45056;                                 // bytes per slab buffer (44 KB): a compile-time ds_read offset
-    char* const wl = smem;                                    // NWB x 16 KB weight ring
-    char* const xl0 = smem + NWB * WBUF;                      // two slab buffers of XB bytes
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int nblocks = a.go.C / 128;
-    const int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
-    const int P = a.gi.P;
-    const int NC = a.gi.C / PFmt<PLANES>::CPL;
-    const int NG = NC * 9;                                    // taps in K order (line-major)
-    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
-    int xoff[MT], qs[MT];
-    bool valid[MT];
-    int slab0, npieces;
-    {
-        const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
-        auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
-        const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
-        slab0 = pos(i0) - P - 1;
-        npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
-            valid[mt] = i < R;
-            qs[mt] = pos(valid[mt] ? i : i1);
-            xoff[mt] = qs[mt] - slab0 - (P + 1);
+    if constexpr (PLANES == 3) {
+        if (a.resid) __syncthreads();                         // weight stages + slab become the waves' residual staging (NBUF tiles each)
+        conv_tail_mx<NT, MT, RESID_NBUF>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096));
+    } else {
+        char* scratch = nullptr;
+        if (PLANES == 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {    // slab memory becomes the waves' residual staging (epilogues)
+            __syncthreads();
+            scratch = xl + wave * 8192;
         }
-    }
-    const char* in_base = (const char*)a.in + (size_t)slab0 * in_pixstride;
-    // weight DMA (waves 2, 3): tap g of the K order = 4 channel tiles x 4 KB; the two waves move 128 pieces per tile.
-    // Buffer addressing: per-lane offset fixed, everything else scalar.
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)a.wpk + (size_t)(nb * 4) * NG * 4096), 0, 4 * NG * 4096, 0x00020000);
-    const int wvoff = (tid & 127) * 16;
-    auto wdma = [&](int g) {
-        char* wb = wl + (g & (NWB - 1)) * WBUF;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-                dma16_buf(wrs, wb + j * 4096 + half * 2048 + (wave - 2) * 1024, wvoff, (j * NG + g) * 4096 + half * 2048);
-    };
-    // slab DMA (waves 0, 1): line c -> buffer c & 1
-    auto xdma = [&](int c) {
-        char* xb = xl0 + (size_t)(c & 1) * XB;
-        for (int i0 = wave * 64; i0 < npieces; i0 += 128) {
-            const int i = i0 + lane;
-            const int Pl = i >> 3, sp = i & 7;
-            const int sl = sp ^ ((Pl >> 1) & 7);
-            dma16(in_base + (size_t)Pl * in_pixstride + c * 128 + sl * 16, xb + (size_t)i0 * 16);
-        }
-    };
-
-    f32x16 acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
-
-    auto wread = [&](bf16x8(&w)[NT][4], int g) {
-        const char* src = wl + (g & (NWB - 1)) * WBUF + (wn * 2) * 4096 + lane * 16;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) w[nt][f] = *(const bf16x8*)(src + nt * 4096 + f * 1024);
-            if constexpr (PLANES == 3)
-                w[nt][3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + nt * 4096 + 3 * 1024), 0u, 0u, 0u});
-        }
-    };
-
-    // prologue: slab 0 and the first three taps' weights
-    if (wave < 2) xdma(0);
-    else { wdma(0); if (NG > 1) wdma(1); if (NG > 2) wdma(2); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    bf16x8 wf[2][NT][4], xf[2][4];
-    wread(wf[0], 0);
-
-    // LDS byte addresses of every (tile row, tap) pixel record and of its scale dword, relative to a slab buffer:
-    // loop-invariant, so the main loop spends no VALU on them beyond the two fragment XORs
-    int xaddr[MT][9], saddr[MT][9];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int Pl = xoff[mt] + (t / 3) * P + (t % 3);
-            xaddr[mt][t] = lds_xbase(Pl, h);
-            saddr[mt][t] = (xaddr[mt][t] ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1));
-        }
-    const char* const xlane = xl0;
-
-    for (int c2 = 0; c2 < NC; c2 += 2) {
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {                   // line parity = slab buffer: a compile-time offset
-            const int c = c2 + par;
-            auto xload = [&](bf16x8(&x)[4], int mt, int t) {
-                const int base = xaddr[mt][t];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) x[f] = *(const bf16x8*)(xlane + par * XB + (base ^ (f << 5)));
-                if constexpr (PLANES == 3)
-                    x[3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(xlane + par * XB + saddr[mt][t]), 0u, 0u, 0u});
-            };
-            if (!(ABL & 2) && wave < 2 && c + 1 < NC) xdma(c + 1);   // lands during this line's nine taps
-            xload(xf[0], 0, 0);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int g = c * 9 + t;
-                constexpr int dummy = 0; (void)dummy;
-                if (!(ABL & 1) && wave >= 2 && g + 3 < NG) wdma(g + 3);
-                if (g + 1 < NG) wread(wf[(par * 9 + t + 1) & 1], g + 1);   // landed before the previous tap's barrier
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int k = t * MT + mt;
-                    if constexpr (!(ABL & 32)) {
-                        if (mt + 1 < MT) xload(xf[(k + 1) & 1], mt + 1, t);
-                        else if (t < 8) xload(xf[(k + 1) & 1], 0, t + 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const bf16x8(&x)[4] = xf[k & 1];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const bf16x8(&w)[4] = wf[(par * 9 + t) & 1][nt];
-                        f32x16& d = acc[nt][mt];
-                        if constexpr (PLANES == 3) {
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
-                            const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-                            const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-                            d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                                                __builtin_bit_cast(i32x4, x[3])[0]);
-                        } else if constexpr (PLANES == 2) {
-                            d = mfma_bf16(w[2], x[0], d);
-                            d = mfma_bf16(w[3], x[1], d);
-                            d = mfma_bf16(w[0], x[2], d);
-                            d = mfma_bf16(w[1], x[3], d);
-                            d = mfma_bf16(w[0], x[0], d);
-                            d = mfma_bf16(w[1], x[1], d);
-                        } else {
-#pragma unroll
-                            for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
-                        }
-                    }
-                }
-                // end of tap g: tap g+2's weights must be in LDS (read into registers during tap g+1); the weight
-                // waves leave only tap g+3's eight DMA instructions in flight.  At a line's last tap the slab waves
-                // wait for the next line's slab.
-                if (wave >= 2) {
-                    if (g + 3 < NG && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (t == 8) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if constexpr (!(ABL & 4)) __syncthreads();
-            }
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = nb * 4 + wn * 2 + nt;
-        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
-        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
+        for (int nt = 0; nt < NT; ++nt) conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, nb * NTILES + wn * NT + nt, lane, scratch);
     }
 }
 
-template <int PLANES, int ABL = 0>
-static int launch_wide2(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = 256, NTHREADS = 256, XB = 45056;
-    if (a.go.C % 128 || (a.gi.C / PFmt<PLANES>::CPL) % 2) return WSI_EINVAL;
-    const int nblocks = a.go.C / 128;
-    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
-    const int mtiles = (int)((R + BM - 1) / BM);
-    const size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + 127) / 128 * 128) * 16;   // two waves stage the slab
-    if (xbytes > XB) return WSI_EINVAL;
-    const size_t lds = 4 * 16384 + 2 * XB;
-    auto k = conv3x3s1_wide2_kernel<PLANES, ABL>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
-    hipLaunchKernelGGL(k, dim3(mtiles * nblocks), dim3(NTHREADS), lds, st, a);
-    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
-}
-
-#endif  // WSI_STUDY
 
 template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
 static int launch_wide(const ConvArgs& a, hipStream_t st) {
@@ -816,8 +468,9 @@ static int launch_wide(const ConvArgs& a, hipStream_t st) {
     const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
     const int mtiles = (int)((R + BM - 1) / BM);
     size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
-    if (xbytes < (size_t)WM * WN * 8192) xbytes = (size_t)WM * WN * 8192;    // residual staging of the epilogue
-    const size_t lds = 2 * (BN / 32) * 4096 + xbytes;
+    if (xbytes < (size_t)WM * WN * 8192) xbytes = (size_t)WM * WN * 8192;    // residual staging of the epilogue (mode 2: in the slab)
+    size_t lds = 2 * (BN / 32) * 4096 + xbytes;
+    if (PLANES == 3 && lds < (size_t)WM * WN * 4 * 4096) lds = (size_t)WM * WN * 4 * 4096;   // mode 3: four residual tiles per wave, from smem + 0
     if (lds > 160 * 1024) return WSI_EINVAL;
     auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -827,48 +480,6 @@ static int launch_wide(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-#ifdef WSI_STUDY   // launcher of the streamed kernel
-static int g_num_cus = 0;
-template <int MT, int WM, int WN, int PLANES, int MINW>
-static int launch_stream(const ConvArgs& a, hipStream_t st) {
-    constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
-    if (a.go.C % (WN * 32)) return WSI_EINVAL;
-    const int nblocks = a.go.C / (WN * 32);
-    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
-    const int mtiles = (int)((R + BM - 1) / BM);
-    // exact largest slab over the tiles of one image period (tile starts repeat with period lcm(BM, H*W) pixels)
-    const int HW = a.gi.H * a.gi.W;
-    auto pos = [&](long long i) { const long long n = i / HW, rem = i - n * HW; return (long long)a.gi.G + n * a.gi.S + (rem / a.gi.W) * a.gi.P + rem % a.gi.W; };
-    long long maxpix = 0;
-    const int scan = mtiles < 4 * HW ? mtiles : 4 * HW;      // BM*HW pixels cover every phase of (tile start mod H*W)
-    for (int m = 0; m < scan; ++m) {
-        const long long i0 = (long long)m * BM, i1 = (i0 + BM < R ? i0 + BM : R) - 1;
-        const long long px = pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1;
-        if (px > maxpix) maxpix = px;
-    }
-    { const long long i0 = (long long)(mtiles - 1) * BM, i1 = R - 1; const long long px = pos(i1) + a.gi.P + 1 - (pos(i0) - a.gi.P - 1) + 1; if (px > maxpix) maxpix = px; }
-    const int bufbytes = (int)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
-    const size_t lds = (size_t)2 * bufbytes;
-    if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_stream_kernel<MT, WM, WN, PLANES, MINW>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return WSI_EINVAL;
-    if (!g_num_cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return WSI_EFAULT;
-        g_num_cus = pr.multiProcessorCount;
-    }
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k, NTHREADS, lds) != hipSuccess || occ < 1) return WSI_EINVAL;
-    const long long total = (long long)mtiles * nblocks;
-    const long long resident = (long long)g_num_cus * occ;
-    const int grid = (int)(total < resident ? total : resident);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a, mtiles, bufbytes);
-    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
-}
-
-#endif  // WSI_STUDY
 
 // --------------------------------------------------------------------------------------------
 // Stride-2 3x3 conv (+ fused 1x1 stride-2 downsample) in slab form.
@@ -940,15 +551,20 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0xffffffff, 0x00020000);
 
     f32x16 acc[MT], accd[FUSE ? MT : 1];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-    if constexpr (FUSE) {
+    if constexpr (PLANES == 3) {                               // mode 3: accumulators start from the folded BN bias
+        acc_init_bias<MT>(acc, a.bias, ntile, lane);
+        if constexpr (FUSE) acc_init_bias<MT>(accd, a.bias2, ntile, lane);
+    } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accd[mt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accd[mt][r] = 0.f;
+        }
     }
     int xoff[MT];
 #pragma unroll
@@ -965,8 +581,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     auto xload = [&](bf16x8(&x)[4], int Pl) {
         const int base = lds_xbase(Pl, h);
 #pragma unroll
-        for (int f = 0; f < (PLANES == 3 ? 3 : 4); ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
-        if constexpr (PLANES == 3) x[3] = lds_xscale(smem, base, Pl);
+        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
     };
     // LDS pixel offset of tap t for tile row 0: region base + back + dy*P + dx
     auto tap_off = [&](int t, int Pc) {
@@ -1012,12 +627,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
                 const bf16x8(&x)[4] = xf[k & 1];
                 f32x16& d = (FUSE && t == 9) ? accd[FUSE ? mt : 0] : acc[mt];
                 if constexpr (PLANES == 3) {
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
-                    const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-                    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-                    d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                                        __builtin_bit_cast(i32x4, x[3])[0]);
+                    d = mfma_mx6(d, w, x);
                 } else if constexpr (PLANES == 2) {
                     d = mfma_bf16(w[2], x[0], d);
                     d = mfma_bf16(w[3], x[1], d);
@@ -1074,7 +684,6 @@ template <int PLANES, bool DENSE>
 __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 2, NT = 2, BM = 256;
-    constexpr int NF = PLANES == 3 ? 3 : 4;
     constexpr int WBUF = 16384, XB = 45056;                   // X: up to 352 pixels (256 real ones + their pads + P + 1), whole DMA rounds
     constexpr int NWB = 4;                                    // weight ring: tap g+3 is requested while tap g multiplies, so a
                                                               // stage has three steps (not one) to arrive from L2
@@ -1148,19 +757,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) w[nt][f] = *(const bf16x8*)(src + nt * 4096 + f * 1024);
-            if constexpr (PLANES == 3)
-                w[nt][3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + nt * 4096 + 3 * 1024), 0u, 0u, 0u});
+            for (int f = 0; f < 4; ++f) w[nt][f] = *(const bf16x8*)(src + nt * 4096 + f * 1024);
         }
     };
 
     f32x16 acc[NT][MT], accd[NT][MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (PLANES == 3) {                           // mode 3: accumulators start from the folded BN bias
+            acc_init_bias<MT>(acc[nt], a.bias, nb * 4 + wn * 2 + nt, lane);
+            acc_init_bias<MT>(accd[nt], a.bias2, nb * 4 + wn * 2 + nt, lane);
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[nt][mt][r] = 0.f; accd[nt][mt][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { acc[nt][mt][r] = 0.f; accd[nt][mt][r] = 0.f; }
+        }
+    }
 
     // per-phase tap lists: {3x3 tap index (9 = downsample), LDS pixel shift in units of (1, P)}
     constexpr int NTAP[4] = {2, 2, 2, 4};
@@ -1206,8 +819,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                         const int Pl = qs[mt] - q0 + sh;
                         const int base = lds_xbase(Pl, h);
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
-                        if constexpr (PLANES == 3) xf[mt][3] = lds_xscale(xl, base, Pl);
+                        for (int f = 0; f < 4; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -1321,15 +933,6 @@ static int launch_gather(const ConvArgs& a, hipStream_t st) {
     X(37, 4, 1, 4, 3, true) \
     X(38, 4, 2, 2, 3, true)
 
-// streamed persistent variants
-#define STREAM_CFGS(X) \
-    X(40, 4, 1, 4, 2) \
-    X(41, 4, 2, 2, 2) \
-    X(42, 4, 1, 2, 2) \
-    X(43, 2, 2, 2, 3) \
-    X(44, 4, 1, 4, 3) \
-    X(45, 2, 2, 4, 3) \
-    X(46, 4, 1, 2, 3)
 
 int wsi_pp_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);      // conv_pp.hip
 
@@ -1348,15 +951,6 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
     if (cfg == 67) return planes == 3 ? launch_wide<3, 1, 0, 4, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 1, 0, 4, 2, 1>(a, st) : WSI_EINVAL;   // 512 px x 64 couts
     if (cfg == 68) return planes == 3 ? launch_wide<3, 2, 0, 2, 2, 1>(a, st) : planes == 2 ? launch_wide<2, 2, 0, 2, 2, 1>(a, st) : WSI_EINVAL;   // 256 px x 64 couts
-    if (cfg == 62) return planes == 3 ? launch_wide2<3>(a, st) : planes == 2 ? launch_wide2<2>(a, st) : launch_wide2<1>(a, st);
-    if (planes == 3 && cfg >= 63 && cfg <= 66) {             // ablations of cfg 62: no weight DMA / no slab DMA / neither / neither + no barriers
-        switch (cfg) {
-        case 63: return launch_wide2<3, 1>(a, st);
-        case 64: return launch_wide2<3, 2>(a, st);
-        case 65: return launch_wide2<3, 3>(a, st);
-        case 66: return launch_wide2<3, 7>(a, st);
-        }
-    }
     if (cfg >= 50 && cfg <= 53 && planes == 3) {             // ablation builds of cfg 30 (bottleneck studies only)
         switch (cfg) {
         case 50: return launch_slab3<4, 1, 4, 3, 2, true, 16>(a, st);
@@ -1366,11 +960,6 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
         }
     }
     switch (cfg) {
-#define X(id, MT, WM, WN, MINW) \
-    case id: return planes == 3 ? launch_stream<MT, WM, WN, 3, MINW>(a, st) \
-                  : planes == 2 ? launch_stream<MT, WM, WN, 2, MINW>(a, st) : launch_stream<MT, WM, WN, 1, MINW>(a, st);
-        STREAM_CFGS(X)
-#undef X
 #define X(id, MT, WM, WN, MINW, DENSE) \
     case id: return planes == 3 ? launch_slab3<MT, WM, WN, 3, MINW, DENSE>(a, st) \
                   : planes == 2 ? launch_slab3<MT, WM, WN, 2, MINW, DENSE>(a, st) : launch_slab3<MT, WM, WN, 1, MINW, DENSE>(a, st);

@@ -125,95 +125,154 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
     }
 }
 
-// Mode-3 epilogue (fp16 hi + MX-fp4).  Lane (pixel, h) owns line positions 16h .. 16h+15 (common.h mx_line_pos):
-// 32 contiguous bytes of fp16 and 8 bytes of each fp4 plane.  Block maxima need one exchange with lane^32; the
-// fp4 planes are swapped between the two lanes so each writes one 16-byte piece (h=0: lo4 of all 32, h=1: hi4).
-// Four store instructions per 32x32 tile (2 x 16 B fp16, 16 B fp4, 4 B scale) and four loads for a residual.
-// Residual: `scratch` (8 KB of LDS private to the wave, or null) selects how the residual tile is read.  Read straight
-// from memory, a load instruction touches 32 different 128-byte lines (one per pixel) and the four loads of a tile cost
-// four TCP look-ups per line: measured 3.8 TB/s on the residual bytes and -18 % on a layer-1 launch when the same bytes
-// are fetched line-contiguously (r01 study).  With scratch the tile (32 lines = 4 KB) is fetched by LDS-DMA, eight lanes
-// per line (pixel indices come from the owning lanes by ds_bpermute; slot swizzle applied on the source side), the
-// next tile's DMA in flight while this one is converted, and each lane then reads its share from LDS.
+// one (pixel tile, channel tile, 32-channel line, tap) step of mode 3: two fp16 MFMAs on the hi planes + one block-scaled
+// fp6 MFMA whose K halves are the two cross terms (lanes h=0: W hi6 x X lo6, lanes h=1: W lo6 x X hi6).  w / x = the four
+// 16-byte fragments of a line as this lane reads them (slots 2f + h): f 0, 1 fp16 k-steps; f 2 = dwords 0-3 of the
+// lane's fp6 plane; f 3 = {dwords 4-5, scale byte, pad}.
+static __device__ __forceinline__ f32x16 mfma_mx6(f32x16 d, const bf16x8 (&w)[4], const bf16x8 (&x)[4]) {
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
+    const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), wr = __builtin_bit_cast(i32x4, w[3]);
+    const i32x4 xq = __builtin_bit_cast(i32x4, x[2]), xr = __builtin_bit_cast(i32x4, x[3]);
+    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], wr[0], wr[1], 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], xr[0], xr[1], 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 2, 2, 0, wr[2], 0, xr[2]);
+}
+
+// Accumulator start values of mode 3: the folded BN bias of this lane's 16 output channels (the epilogue then adds nothing)
 template <int MT>
+static __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MT], const float* bias, int ntile, int lane) {
+    const int h = lane >> 5;
+    float b[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(bias + ntile * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[4 * g + i] = v[i];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = b[r];
+}
+
+// Mode-3 epilogue (fp16 hi + MX-fp6): acc (bias and residual already inside: acc_init_bias, conv_tail_mx) -> clamp /
+// ReLU -> the next layer's operands, for tiles mt0 .. mt0 + MTN - 1.  Lane (pixel, h) owns line positions 16h .. 16h+15 of the fp16 plane (32 contiguous
+// bytes) and, after one exchange with lane ^ 32 (v_permlane32_swap per register), ALL 32 values of one fp6 plane (h = 0:
+// lo6, h = 1: hi6), which one v_cvt_scalef32_2xpk16_fp6_f32 converts.  Four 16-byte stores per 32x32 tile; the whole
+// 128-byte line is written.  (`a.resid` is not read here: conv_tail_mx adds the residual.)
+template <int MT, int MTN = MT>
 static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
-                                                        const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
-    const int h = lane >> 5, l31 = lane & 31;
+                                                        const bool (&valid)[MT], int ntile, int lane, int mt0 = 0) {
+    const int h = lane >> 5;
     const size_t pixstride = (size_t)a.go.C * 4;
-    float bias[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
     const float lo_clamp = a.relu ? 0.f : -65504.f;
-    const bool via_lds = a.resid && scratch;
-    auto rdma = [&](int mt) {                                 // residual tile mt -> scratch buffer mt & 1
-        resid_tile_dma(a.resid, valid[mt] ? qs[mt] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch + (mt & 1) * 4096);
-    };
-    if (via_lds) rdma(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = mt0; mt < mt0 + MTN; ++mt) {
         const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * 128;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[mt][r] + bias[r];
-        if (a.resid) {
-            f16x8 r0, r1;
-            uint2 nib;
-            unsigned rs;
-            if (via_lds) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // tile mt has landed (and the previous tile's stores)
-                if (mt + 1 < MT) rdma(mt + 1);
-                const char* t = scratch + (mt & 1) * 4096 + l31 * 128;
-                const int sw = (l31 >> 1) & 7;
-                r0 = *(const f16x8*)(t + (((2 * h) ^ sw) << 4));
-                r1 = *(const f16x8*)(t + (((2 * h + 1) ^ sw) << 4));
-                nib = *(const uint2*)(t + ((4 ^ sw) << 4) + 8 * h);
-                rs = *(const unsigned*)(t + ((6 ^ sw) << 4)) & 255u;
-            } else {
-                const char* rl = (const char*)a.resid + loff;
-                r0 = *(const f16x8*)(rl + 32 * h);
-                r1 = *(const f16x8*)(rl + 32 * h + 16);
-                nib = *(const uint2*)(rl + 64 + 8 * h);                              // lo4 of this lane's 16 positions
-                rs = *(const unsigned*)(rl + 96) & 255u;                             // residual's scale_lo
-            }
-            const float rscale = rs ? mx4_scale_value((int)rs) : 0.f;
-            float d[16];
-            mx4_unpack8(nib.x, rscale, d);
-            mx4_unpack8(nib.y, rscale, d + 8);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                v[r] += (float)r0[r] + d[r];
-                v[8 + r] += (float)r1[r] + d[8 + r];
-            }
-        }
-        float lo[16], mh = 0.f, ml = 0.f;
+        f32x16 v = acc[mt];
+        f32x16 hi, lo;
         f16x8 hv[2];
+        float mv = 0.f, ml = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = __builtin_amdgcn_fmed3f(v[r], lo_clamp, 65504.f);              // ReLU (if any) + fp16-range clamp in one op
-            const _Float16 hh = (_Float16)v[r];
-            hv[r >> 3][r & 7] = hh;
-            lo[r] = v[r] - (float)hh;
-            v[r] = (float)hh;                                                       // v now holds hi
-            mh = fmaxf(mh, fabsf(v[r]));
-            ml = fmaxf(ml, fabsf(lo[r]));
+        for (int r = 0; r < 16; r += 2) {
+            const float v0 = __builtin_amdgcn_fmed3f(v[r], lo_clamp, 65504.f);      // ReLU (if any) + fp16-range clamp in one op
+            const float v1 = __builtin_amdgcn_fmed3f(v[r + 1], lo_clamp, 65504.f);
+            const f16x2 hh = __builtin_convertvector(f32x2{v0, v1}, f16x2);          // v_cvt_pk_f16_f32 (RNE)
+            hv[r >> 3][r & 7] = hh[0];
+            hv[r >> 3][(r & 7) + 1] = hh[1];
+            hi[r] = (float)hh[0];
+            hi[r + 1] = (float)hh[1];
+            lo[r] = v0 - hi[r];
+            lo[r + 1] = v1 - hi[r + 1];
+            mv = fmaxf(mv, fmaxf(fabsf(hi[r]), fabsf(hi[r + 1])));
+            ml = fmaxf(ml, fmaxf(fabsf(lo[r]), fabsf(lo[r + 1])));
         }
-        mh = fmaxf(mh, __shfl_xor(mh, 32));
-        ml = fmaxf(ml, __shfl_xor(ml, 32));
-        const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
-        const float fh = sh ? mx4_scale_value(sh) : 1.f, fl = sl ? mx4_scale_value(sl) : 1.f;
-        const unsigned ql[2] = {mx4_pack8(lo, fl), mx4_pack8(lo + 8, fl)}, qh[2] = {mx4_pack8(v, fh), mx4_pack8(v + 8, fh)};
-        // lane h=0 keeps lo4 and receives the partner's lo4; lane h=1 keeps hi4 and receives the partner's hi4
-        const unsigned s0 = __shfl_xor(h ? ql[0] : qh[0], 32), s1 = __shfl_xor(h ? ql[1] : qh[1], 32);
-        const u32x4 q4 = h ? u32x4{s0, s1, qh[0], qh[1]} : u32x4{ql[0], ql[1], s0, s1};
+        pair_max2(mv, ml);                                                            // block maxima over the pixel's two lanes
+        const int sh = mx6_scale_byte(mv), sl = mx6_scale_byte(ml);
+        const int sb = h ? sh : sl;                                                   // this lane's plane: h = 0 lo6, h = 1 hi6
+        swap32_halves(lo, hi);                                                        // lo := (h ? partner's hi : own lo), hi := (h ? own hi : partner's lo)
+        const u32x6 q = mx6_pack32(lo, hi, sb ? mx_scale_value(sb) : 1.f);
         if (valid[mt] && !CONV_STUDY(a, CONV_ABL_NO_STORE)) {
             char* ol = (char*)a.out + (a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, qs[mt], pixstride) + (size_t)ntile * 128 : loff);
             *(f16x8*)(ol + 32 * h) = hv[0];
             *(f16x8*)(ol + 32 * h + 16) = hv[1];
-            *(u32x4*)(ol + 64 + 16 * h) = q4;
-            const unsigned sc = (unsigned)(h ? sh : sl);                          // replicated: the whole 128-byte line is written
-            *(u32x4*)(ol + 96 + 16 * h) = u32x4{sc, sc, sc, sc};              // (no partial-line writes), readers pick any dword
+            *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
+            *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
+        }
+    }
+}
+
+// Mode-3 tail of a conv kernel: (residual) + clamp / ReLU + line encode + store of all NT x MT accumulator tiles of a wave.
+// Residual: acc[nt][mt] += residual tile, through the matrix pipe.  The tiles (32 pixels x one 128-byte line each) are
+// fetched by LDS-DMA into `scratch` (NBUF x 4 KB, private to the wave), eight lanes per line, in the swizzled slab image
+// (resid_tile_dma); a tile is then the B operand of one mode-3 MFMA step whose A operand is the identity: 1.0 at the K
+// position of the lane's own channel in the fp16 plane and in the hi6 plane (K half 0, which multiplies the residual's
+// lo6 plane), zeros in the lo6 plane - so the step adds exactly hi + lo6 * 2^(scale_lo - 127), the value the line stores.
+// Tiles go in batches of NBUF (channel tile major): the DMA of batch b + 1 is in flight while batch b is encoded and
+// stored, so a wave pays one exposed round trip to memory instead of one per tile (r02: vector decode of ~50 instructions
+// per tile and 4-8 round trips in a row per wave, +20 % on a residual launch).  Only `vmcnt(0)` waits: spill code or
+// stores the compiler places between the DMAs cannot break a counted wait.
+template <int NT, int MT, int NBUF>
+static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&acc)[NT][MT], const int (&qs)[MT], const bool (&valid)[MT],
+                                                    int ntile0, int lane, char* scratch) {
+    constexpr int T = NT * MT;
+    static_assert(MT % NBUF == 0 || NBUF % MT == 0, "a batch is part of one channel tile or whole channel tiles");
+    if (!a.resid) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile0 + nt, lane);
+        return;
+    }
+    const int h = lane >> 5, l31 = lane & 31;
+    const size_t pixstride = (size_t)a.go.C * 4;
+    bf16x8 iw[4];
+    {
+        const int p = mx_line_pos(l31), f0 = mx6_field_of_pos(p);
+        f16x8 k0, k1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            k0[j] = (p == 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
+            k1[j] = (p == 16 + 8 * h + j) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+        unsigned q[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {                           // code 8 (= 1.0) in field f0 of the h = 0 lanes: bit 6 f0 + 3
+            const int bit = 6 * f0 + 3 - 32 * d;
+            q[d] = (h == 0 && bit >= 0 && bit < 32) ? (1u << (bit & 31)) : 0u;
+        }
+        iw[0] = __builtin_bit_cast(bf16x8, k0);
+        iw[1] = __builtin_bit_cast(bf16x8, k1);
+        iw[2] = __builtin_bit_cast(bf16x8, u32x4{q[0], q[1], q[2], q[3]});
+        iw[3] = __builtin_bit_cast(bf16x8, u32x4{q[4], q[5], 127u, 0u});
+    }
+    auto rdma = [&](int k) {
+        const int nt = k / MT, mt = k % MT;
+        resid_tile_dma(a.resid, valid[mt] ? qs[mt] : a.go.G, pixstride, (size_t)(ntile0 + nt) * 128, lane, scratch + (k % NBUF) * 4096);
+    };
+    const int xb = l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
+#pragma unroll
+    for (int k = 0; k < NBUF; ++k) rdma(k);
+#pragma unroll
+    for (int b0 = 0; b0 < T; b0 += NBUF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // batch b0 has landed (and the previous batch's stores)
+#pragma unroll
+        for (int k = b0; k < b0 + NBUF; ++k) {
+            const char* t = scratch + (k % NBUF) * 4096;
+            bf16x8 x[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(t + (xb ^ (f << 5)));
+            acc[k / MT][k % MT] = mfma_mx6(acc[k / MT][k % MT], iw, x);
+        }
+        if (b0 + NBUF < T) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the batch is in registers: its buffers take the next one
+#pragma unroll
+            for (int k = b0 + NBUF; k < b0 + 2 * NBUF; ++k) rdma(k);
+        }
+        // encode + store this batch while the next one is in flight
+        if constexpr (NBUF >= MT) {
+#pragma unroll
+            for (int nt = b0 / MT; nt < (b0 + NBUF) / MT; ++nt) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile0 + nt, lane);
+        } else {
+            conv_epilogue_mx<MT, NBUF>(a, acc[b0 / MT], qs, valid, ntile0 + b0 / MT, lane, b0 % MT);
         }
     }
 }
@@ -242,7 +301,7 @@ static __device__ __forceinline__ void conv_epilogue_any(const ConvArgs& a, f32x
             qs[mt] = q_base + mt * 32 + (lane & 31);
             valid[mt] = pf_is_pixel(a.go, qs[mt]);
         }
-        conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);
+        conv_epilogue_mx<MT>(a, acc, qs, valid, ntile, lane);                  // (acc started from the bias: acc_init_bias)
     } else {
         conv_epilogue<MT, PLANES>(a, acc, q_base, ntile, lane);
     }
@@ -280,23 +339,11 @@ static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8
 // LDS byte offset of slot-pair base for slab-local pixel Pl and lane half h (swizzled):
 // slot s = 2f + h is stored at slot s ^ ((Pl>>1)&7); fragment f is reached by XOR (f<<5).
 static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128 + ((h ^ ((Pl >> 1) & 7)) << 4); }
-// Mode 3: the block-scale dword of pixel Pl (slot 6 + h, replicated in all four dwords of the slot).  Reading dword
-// (Pl & 1) + 2 * ((Pl >> 4) & 1) spreads 32 consecutive pixels over all 32 banks of a ds_read_b32.
-static __device__ __forceinline__ bf16x8 lds_xscale(const char* smem, int base, int Pl) {
-    const unsigned sc = *(const unsigned*)(smem + (base ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1)));
-    return __builtin_bit_cast(bf16x8, u32x4{sc, 0u, 0u, 0u});
-}
-
 // one (pixel tile, channel tile, 32-channel line, tap) step of every precision mode
 template <int PLANES>
 static __device__ __forceinline__ void mfma_step(f32x16& d, const bf16x8 (&w)[4], const bf16x8 (&x)[4]) {
     if constexpr (PLANES == 3) {
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, x[0]), d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
-        const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), xq = __builtin_bit_cast(i32x4, x[2]);
-        const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], 0, 0, 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], 0, 0, 0, 0};
-        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 4, 4, 0, __builtin_bit_cast(i32x4, w[3])[0], 0,
-                                                            __builtin_bit_cast(i32x4, x[3])[0]);
+        d = mfma_mx6(d, w, x);
     } else if constexpr (PLANES == 2) {
         d = mfma_bf16(w[2], x[0], d);
         d = mfma_bf16(w[3], x[1], d);

@@ -37,7 +37,8 @@ template <int PLANES, int WM, int WN, int MT, bool STAMP = false, int DMODE = 0,
 __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xbytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 2, BM = WM * MT * 32, NTILES = WN * NT, WB = NTILES * 4096;
-    constexpr int NF = PLANES == 3 ? 3 : 4;                   // 16-byte fragments per operand set (+ scale dword in mode 3)
+    constexpr int NF = 4;                                     // 16-byte fragments per operand set
+    constexpr int RESID_NBUF = 4;                             // mode 3: residual tiles in flight per wave (epilogue; 128 KB of the dead LDS)
     static_assert(WM * WN == 8, "eight waves: two groups of four, one wave of each group per SIMD");
     char* const wl = smem;                                    // 2 weight stages of NTILES x 4 KB
     char* const xl = smem + 2 * WB;                           // 2 pixel slabs of xbytes
@@ -111,16 +112,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
 
     f32x16 acc[NT][MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (PLANES == 3) acc_init_bias<MT>(acc[nt], a.bias, nb * NTILES + wn * NT + nt, lane);   // mode 3: start from the folded BN bias
+        else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+        }
+    }
 
     // LDS byte addresses of one tap's pixel fragments (and scale dwords), relative to smem: computed one step ahead,
     // inside the previous multiply phase (VALU beside MFMA is nearly free; in the load phase these ~12 instructions per
     // tile row delayed the reads: r02 counters)
-    int xaddr[MT][NF], saddr[MT];
+    int xaddr[MT][NF];
     auto tap_addrs = [&](int slab_off, int toff) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -130,10 +135,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
             const int base = lds_xbase(Pl, h);
 #pragma unroll
             for (int f = 0; f < NF; ++f) xaddr[mt][f] = slab_off + (base ^ (f << 5));
-            saddr[mt] = slab_off + (base ^ (3 << 5)) + 4 * ((Pl & 1) + 2 * ((Pl >> 4) & 1));
             // ... and finished here (a second pin: hipcc otherwise sinks the arithmetic down to the reads, past the barrier)
-            if constexpr (NF == 3) asm volatile("" : "+v"(xaddr[mt][0]), "+v"(xaddr[mt][1]), "+v"(xaddr[mt][2]), "+v"(saddr[mt]));
-            else asm volatile("" : "+v"(xaddr[mt][0]), "+v"(xaddr[mt][1]), "+v"(xaddr[mt][2]), "+v"(xaddr[mt][NF - 1]));
+            asm volatile("" : "+v"(xaddr[mt][0]), "+v"(xaddr[mt][1]), "+v"(xaddr[mt][2]), "+v"(xaddr[mt][3]));
         }
     };
     const int wlane = (wn * NT) * 4096 + lane * 16;           // this lane's slot inside a weight stage
@@ -185,13 +188,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
                 const char* src = wcur + wlane + nt * 4096;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) wf[nt][f] = *(const bf16x8*)(src + f * 1024);
-                if constexpr (PLANES == 3) wf[nt][3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(src + 3 * 1024), 0u, 0u, 0u});
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int f = 0; f < NF; ++f) xf[mt][f] = *(const bf16x8*)(smem + xaddr[mt][f]);
-                if constexpr (PLANES == 3) xf[mt][3] = __builtin_bit_cast(bf16x8, u32x4{*(const unsigned*)(smem + saddr[mt]), 0u, 0u, 0u});
             }
             // group B's share of the next stage must be complete before group A reads it, one barrier from here (B has been
             // waiting for its fragments meanwhile); group A's share and slab slices get the whole multiply phase below
@@ -242,13 +243,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
     }
 #endif
     if (grp == 0) PP_BARRIER();                               // group A's matching extra barrier
-    char* scratch = nullptr;
-    if (PLANES >= 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) scratch = xl + wave * 8192;   // slabs are dead: residual staging
+    if constexpr (PLANES == 3) {                              // weight stages and slabs are dead: residual staging, NBUF tiles per wave
+        conv_tail_mx<NT, MT, (RESID_NBUF % MT == 0 ? RESID_NBUF : MT)>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096));
+    } else {
+        char* scratch = nullptr;
+        if (PLANES == 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) scratch = xl + wave * 8192;   // slabs are dead: residual staging
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = nb * NTILES + wn * NT + nt;
-        if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane, scratch);
-        else conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane, scratch);
+        for (int nt = 0; nt < NT; ++nt) conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, nb * NTILES + wn * NT + nt, lane, scratch);
     }
 }
 
@@ -262,8 +263,9 @@ static int launch_pp(const ConvArgs& a, hipStream_t st) {
     const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
     const int mtiles = (int)((R + BM - 1) / BM);
     size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + 63) / 64 * 64) * 16;         // whole 1 KB DMA instructions
-    if (2 * xbytes < 8 * 8192) xbytes = 8 * 8192 / 2;                                          // residual staging of the epilogue
-    const size_t lds = 2 * (size_t)(BN / 32) * 4096 + 2 * xbytes;
+    if (2 * xbytes < 8 * 8192) xbytes = 8 * 8192 / 2;                                          // residual staging of the epilogue (mode 2: in the slabs)
+    size_t lds = 2 * (size_t)(BN / 32) * 4096 + 2 * xbytes;
+    if (PLANES == 3 && lds < 8 * 4 * 4096) lds = 8 * 4 * 4096;                                // mode 3: four residual tiles per wave, from smem + 0
     if (lds > 160 * 1024 || xbytes > 65536) return WSI_EINVAL;                                 // (group B moves a slab in <= 16 rounds)
     auto k = conv3x3s1_pp_kernel<PLANES, WM, WN, MT, STAMP, DMODE, PRIO>;
     static bool lds_ok = false;                              // once per instantiation: up to the whole 160 KB

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const void* in, PFGeom 
     const float inv = 1.0f / (float)(g.H * g.W);
     if constexpr (PLANES == 3) {
         // Thread t owns one 16-byte slice (8 line positions) of 32-channel line (t >> 2) mod NL, for pixels t / (4 NL),
-        // + 256 / (4 NL), ...: whole lines are read by 4 neighbouring lanes (coalesced 64 B of fp16 + their fp4 / scale),
+        // + 256 / (4 NL), ...: whole lines are read by 4 neighbouring lanes (coalesced 64 B of fp16 + the lo6 plane / scale),
         // partial sums meet in LDS.  (The per-channel form read 2 bytes per access: 0.125 ms per 1000 patches.)
         const int NL = g.C / 32, HW = g.H * g.W;
         float* part = f + g.C;                                  // [256 / (4 NL) pixel groups][C] partial sums (launcher sizes it)
@@ -34,10 +34,15 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const void* in, PFGeom 
                 const int y = p / g.W, x = p - y * g.W;
                 const char* L = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * pixstride + (size_t)line * 128;
                 const f16x8 hi = *(const f16x8*)(L + 16 * slice);
-                const unsigned lo4 = *(const unsigned*)(L + 64 + 4 * slice);          // positions 8*slice .. 8*slice+7
-                const unsigned sl = *(const unsigned*)(L + 96) & 255u;
-                float d[8];
-                mx4_unpack8(lo4, sl ? mx4_scale_value((int)sl) : 0.f, d);
+                const u32x4 p0 = *(const u32x4*)(L + MX6_PLANE_LO(0)), p1 = *(const u32x4*)(L + MX6_PLANE_HI(0));   // lo6 plane + {rest, scale_lo}
+                const unsigned sl = p1[2] & 255u;
+                const f32x32 dd = mx6_unpack32(u32x6{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1]}, sl ? mx_scale_value((int)sl) : 0.f);
+                float d[8];                                                           // position 8 slice + i = field 16 (slice & 1) + 2 i + (slice >> 1)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float e0 = (slice >> 1) ? dd[2 * i + 1] : dd[2 * i], e1 = (slice >> 1) ? dd[16 + 2 * i + 1] : dd[16 + 2 * i];
+                    d[i] = (slice & 1) ? e1 : e0;
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sm[i] += (float)hi[i] + d[i];
             }

@@ -3,48 +3,62 @@
 #pragma once
 #include "common.h"
 
-// nearest fp4 (e2m1) code, round-to-nearest-even, saturating (same rule as v_cvt_scalef32_pk_fp4_f32 and the host prepack)
-static __device__ __forceinline__ unsigned fp4_encode_dev(float y) {
-    const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
-    const float a = fabsf(y);
-    int best = 7;
-#pragma unroll
-    for (int i = 6; i >= 0; --i) {
-        const float mid = 0.5f * (mag[i] + mag[i + 1]);
-        if (a < mid || (a == mid && (i & 1) == 0)) best = i;
-    }
-    return (unsigned)best | ((__float_as_uint(y) >> 31) ? 8u : 0u);
-}
-
-// mode-3 line codec for one pixel line (32 channels): v[32] -> 128 bytes, and back
+// mode-3 line codec for one pixel line (32 channels): v[32] (channel order) -> 128 bytes, and back.  Scalar reference form
+// of what the conv epilogues do with v_cvt_scalef32_2xpk16_fp6_f32 (same rounding, same scales, same layout).
 static __device__ void mx_line_encode(const float* v, char* line) {
     float hi[32], lo[32], mh = 0.f, ml = 0.f;
-    for (int c = 0; c < 32; ++c) {                        // c = line position (mx_line_pos order)
-        const float t = v[mx_line_chan(c)];
+    for (int c = 0; c < 32; ++c) {                        // c = fp16 line position (mx_line_pos order)
+        const float t = fminf(fmaxf(v[mx_line_chan(c)], -65504.f), 65504.f);
         hi[c] = (float)(_Float16)t;
         lo[c] = t - hi[c];
         mh = fmaxf(mh, fabsf(hi[c]));
         ml = fmaxf(ml, fabsf(lo[c]));
     }
-    const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
-    const float ih = sh ? 1.0f / mx4_scale_value(sh) : 0.f, il = sl ? 1.0f / mx4_scale_value(sl) : 0.f;
+    const int sh = mx6_scale_byte(mh), sl = mx6_scale_byte(ml);
+    const float ih = sh ? 1.0f / mx_scale_value(sh) : 0.f, il = sl ? 1.0f / mx_scale_value(sl) : 0.f;
     for (int c = 0; c < 32; ++c) ((_Float16*)line)[c] = (_Float16)hi[c];
-    for (int b = 0; b < 16; ++b) {
-        line[64 + b] = (char)(fp4_encode_dev(lo[2 * b] * il) | (fp4_encode_dev(lo[2 * b + 1] * il) << 4));
-        line[80 + b] = (char)(fp4_encode_dev(hi[2 * b] * ih) | (fp4_encode_dev(hi[2 * b + 1] * ih) << 4));
+    unsigned pl[6] = {0u, 0u, 0u, 0u, 0u, 0u}, ph[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        mx6_set_field(pl, mx6_field_of_pos(c), fp6_encode(lo[c] * il));
+        mx6_set_field(ph, mx6_field_of_pos(c), fp6_encode(hi[c] * ih));
     }
-    for (int b = 0; b < 16; b += 4) {                     // scales replicated over their 16-byte slots
-        *(unsigned*)(line + 96 + b) = (unsigned)sl;
-        *(unsigned*)(line + 112 + b) = (unsigned)sh;
-    }
+    unsigned* w = (unsigned*)line;
+    for (int d = 0; d < 4; ++d) { w[16 + d] = pl[d]; w[20 + d] = ph[d]; }
+    w[24] = pl[4]; w[25] = pl[5]; w[26] = (unsigned)sl; w[27] = 0u;
+    w[28] = ph[4]; w[29] = ph[5]; w[30] = (unsigned)sh; w[31] = 0u;
 }
-static __device__ __forceinline__ float mx_line_decode(const char* line, int chan) {  // x = hi + lo4 * 2^(scale_lo-127)
+// the lo6 plane of a line as six dwords + its scale (0 for an all-zero block)
+static __device__ __forceinline__ float mx_line_lo_plane(const char* line, unsigned (&pl)[6]) {
+    const unsigned* w = (const unsigned*)line;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) pl[d] = w[16 + d];
+    pl[4] = w[24];
+    pl[5] = w[25];
+    const unsigned sl = w[26] & 255u;
+    return sl ? mx_scale_value((int)sl) : 0.f;
+}
+static __device__ __forceinline__ float mx_line_decode(const char* line, int chan) {  // x = hi + lo6 * 2^(scale_lo-127)
     const int c = mx_line_pos(chan);
-    const unsigned sl = *(const unsigned*)(line + 96) & 255u;
-    const unsigned nib = ((unsigned)(unsigned char)line[64 + (c >> 1)] >> (4 * (c & 1))) & 15u;
-    return (float)((const _Float16*)line)[c] + (sl ? fp4_value(nib) * mx4_scale_value((int)sl) : 0.f);
+    unsigned pl[6];
+    const float sc = mx_line_lo_plane(line, pl);
+    return (float)((const _Float16*)line)[c] + fp6_value(mx6_get_field(pl, mx6_field_of_pos(c))) * sc;
 }
-
+// all 32 values of a line in fp16 POSITION order (position p holds channel mx_line_chan(p)): 16-byte loads + one
+// v_cvt_scalef32_pk32_f32_fp6
+static __device__ __forceinline__ void mx_line_decode_all(const char* line, float (&a)[32]) {
+    const uint4* q = (const uint4*)line;
+    const uint4 h0 = q[0], h1 = q[1], h2 = q[2], h3 = q[3], p0 = q[4], p1 = q[6];
+    const unsigned sl = p1.z & 255u;
+    const f32x32 d = mx6_unpack32(u32x6{p0.x, p0.y, p0.z, p0.w, p1.x, p1.y}, sl ? mx_scale_value((int)sl) : 0.f);
+    const uint4 hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f16x8 v = __builtin_bit_cast(f16x8, hh[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[8 * j + i] = (float)v[i] + d[2 * ((8 * j + i) & 15) + ((8 * j + i) >> 4)];
+    }
+}
 
 // any precision mode: line = 32 channels (planes 2, 3) or 64 (planes 1); v[] in channel order
 template <int PLANES>

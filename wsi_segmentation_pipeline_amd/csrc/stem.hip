@@ -462,32 +462,35 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
             const bool store = (even ? !(l31 & 1) : ((l31 & 1) && l31 <= 29)) && px < Wp;
             char* o = (char*)A.out_pf + (size_t)(go.G + n * go.S + py * go.P + (store ? px : 0)) * pixstride;
             if constexpr (OUT == 3) {
-                // fp16 hi + MX-fp4 (hi4, lo4) with one scale per 32-channel line; the line's channels sit in lanes l, l^32
-                float hi[16], lo[16], mh = 0.f, ml = 0.f;
+                // fp16 hi + MX-fp6 (lo6, hi6) with one scale per plane and 32-channel line; the line's channels sit in lanes l, l^32
+                // (same encode as conv_epilogue_mx: conv_dev.h)
+                f32x16 hi, lo;
                 f16x8 hv[2];
+                float mh = 0.f, ml = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const _Float16 hh = (_Float16)fminf(v[r], 65504.f);
-                    hv[r >> 3][r & 7] = hh;
-                    hi[r] = (float)hh;
-                    lo[r] = fminf(v[r], 65504.f) - hi[r];
-                    mh = fmaxf(mh, fabsf(hi[r]));
-                    ml = fmaxf(ml, fabsf(lo[r]));
+                for (int r = 0; r < 16; r += 2) {
+                    const float v0 = fminf(v[r], 65504.f), v1 = fminf(v[r + 1], 65504.f);
+                    const f16x2 hh = __builtin_convertvector(f32x2{v0, v1}, f16x2);
+                    hv[r >> 3][r & 7] = hh[0];
+                    hv[r >> 3][(r & 7) + 1] = hh[1];
+                    hi[r] = (float)hh[0];
+                    hi[r + 1] = (float)hh[1];
+                    lo[r] = v0 - hi[r];
+                    lo[r + 1] = v1 - hi[r + 1];
+                    mh = fmaxf(mh, fmaxf(hi[r], hi[r + 1]));                                // (v >= 0 after the ReLU)
+                    ml = fmaxf(ml, fmaxf(fabsf(lo[r]), fabsf(lo[r + 1])));
                 }
-                mh = fmaxf(mh, __shfl_xor(mh, 32));
-                ml = fmaxf(ml, __shfl_xor(ml, 32));
-                const int sh = mx4_scale_byte(mh), sl = mx4_scale_byte(ml);
-                const float fh = sh ? mx4_scale_value(sh) : 1.f, fl = sl ? mx4_scale_value(sl) : 1.f;
-                const unsigned ql[2] = {mx4_pack8(lo, fl), mx4_pack8(lo + 8, fl)}, qh[2] = {mx4_pack8(hi, fh), mx4_pack8(hi + 8, fh)};
-                const unsigned s0 = __shfl_xor(h ? ql[0] : qh[0], 32), s1 = __shfl_xor(h ? ql[1] : qh[1], 32);
-                const u32x4 q4 = h ? u32x4{s0, s1, qh[0], qh[1]} : u32x4{ql[0], ql[1], s0, s1};
-                if (store) {                                                        // line order: common.h mx_line_pos
+                pair_max2(mh, ml);
+                const int sh = mx6_scale_byte(mh), sl = mx6_scale_byte(ml);
+                const int sb = h ? sh : sl;
+                swap32_halves(lo, hi);
+                const u32x6 q = mx6_pack32(lo, hi, sb ? mx_scale_value(sb) : 1.f);
+                if (store) {                                                        // line order: common.h mx_line_pos / mx6_field_of_pos
                     char* ol = o + wave * 128;
                     *(f16x8*)(ol + 32 * h) = hv[0];
                     *(f16x8*)(ol + 32 * h + 16) = hv[1];
-                    *(u32x4*)(ol + 64 + 16 * h) = q4;
-                    const unsigned sc = (unsigned)(h ? sh : sl);
-                    *(u32x4*)(ol + 96 + 16 * h) = u32x4{sc, sc, sc, sc};
+                    *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
+                    *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
                 }
             } else if (store) {
 #pragma unroll

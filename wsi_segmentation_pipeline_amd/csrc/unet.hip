@@ -67,18 +67,7 @@ template <int PLANES>
 static __device__ __forceinline__ void head_line_decode(const char* line, float (&a)[PFmt<PLANES>::CPL]) {
     const uint4* q = (const uint4*)line;
     if constexpr (PLANES == 3) {
-        const uint4 h0 = q[0], h1 = q[1], h2 = q[2], h3 = q[3], lo4 = q[4];
-        const unsigned sl = *(const unsigned*)(line + 96) & 255u;
-        const float sc = sl ? mx4_scale_value((int)sl) : 0.f;
-        float d[32];
-        mx4_unpack8(lo4.x, sc, d); mx4_unpack8(lo4.y, sc, d + 8); mx4_unpack8(lo4.z, sc, d + 16); mx4_unpack8(lo4.w, sc, d + 24);
-        const uint4 hh[4] = {h0, h1, h2, h3};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16x8 v = __builtin_bit_cast(f16x8, hh[j]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[8 * j + i] = (float)v[i] + d[8 * j + i];
-        }
+        mx_line_decode_all(line, a);
     } else if constexpr (PLANES == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
