@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WSI_HIP_ABI_VERSION 2
+#define WSI_HIP_ABI_VERSION 3
 int wsi_hip_abi_version(void);
 
 /* ---- padded-flat layout helpers (host) -------------------------------------------------------
@@ -194,8 +194,11 @@ int wsi_softmax_threshold_argmax(const double* pred, int c, long long hw, const 
  *                     decode into wsi_ring_host_slot (any thread) -> wsi_ring_submit (one thread at a time): async H2D + unpack of
  *                     `rows` x `width` pixels of `channels` (3, or 4 with the alpha byte dropped like PIL convert('RGB')) bytes,
  *                     row pitch src_pitch, into level_rows (device pointer to the first destination row, pitch level_pitch).
- *                     wsi_ring_fence makes compute_stream wait for everything submitted so far (no host block); wsi_ring_drain
- *                     blocks the host.  Nothing here touches the compute stream otherwise: decode, copies and the trunk overlap.
+ *                     wsi_ring_acquire (before the first submit into memory allocated on compute_stream) makes the copy stream wait
+ *                     for everything enqueued on compute_stream so far - the destination may be a recycled block that queued
+ *                     kernels still read; wsi_ring_fence makes compute_stream wait for everything submitted so far (neither blocks
+ *                     the host); wsi_ring_drain blocks the host.  Nothing else touches the compute stream: decode, copies and the
+ *                     trunk overlap.  A ring belongs to the device current at its creation (wsi_ring_device).
  *   wsi_resample_*    the scan_resize != 1 branch (utils/dataset.py:180-181 `image.resize((tile_w, tile_h))`, Pillow's default
  *                     BICUBIC): n tiles of (in_h, in_w) read from the u8 slide at tile_xy (out-of-slide pixels 0) -> out
  *                     (n, out_h, out_w, 3) u8, bit-exact with Pillow (22-bit fixed-point taps, horizontal then vertical pass, u8
@@ -207,7 +210,9 @@ int wsi_ring_create(wsi_ring** out, int slots, size_t slot_bytes);
 void* wsi_ring_host_slot(wsi_ring* ring, int slot);
 int wsi_ring_wait_slot(wsi_ring* ring, int slot);
 int wsi_ring_submit(wsi_ring* ring, int slot, int rows, int width, int channels, long long src_pitch, uint8_t* level_rows, long long level_pitch);
+int wsi_ring_acquire(wsi_ring* ring, void* compute_stream);
 int wsi_ring_fence(wsi_ring* ring, void* compute_stream);
+int wsi_ring_device(const wsi_ring* ring);
 int wsi_ring_drain(wsi_ring* ring);
 void wsi_ring_destroy(wsi_ring* ring);
 int wsi_resample_plan_create(wsi_resample_plan** out, int in_h, int in_w, int out_h, int out_w);

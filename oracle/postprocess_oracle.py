@@ -215,15 +215,17 @@ def tumor_bed_iou(tb_gt, tb_pred, epsilon=1e-8):
 
 
 def wsi_scores(p, gt, mask, epsilon=1e-8):
-    """utils/eval.py:107-121 (operator precedence kept: `1 - gt > 0` is `(1 - gt) > 0`): dict of
-    acc, s, acc_masked, s_masked, iou_fg for a class map p, ground truth gt and foreground mask."""
+    """utils/eval.py:107-121: dict of acc, s, acc_masked, s_masked, iou_fg for a class map p (np.argmax: int64), ground truth gt
+    and foreground mask.  Operator precedence AND dtypes kept: `1 - gt > 0` is `(1 - gt) > 0` on the uint8 array of a PIL image
+    (utils/eval.py:76-78), where 1 - gt wraps (0 -> 1, 1 -> 0, 2 -> 255, 3 -> 254): the factor is gt != 1."""
     p = np.asarray(p).astype(np.int64)
-    gt = np.asarray(gt).astype(np.int64)
+    gt8 = np.asarray(gt).astype(np.uint8)
+    gt = gt8.astype(np.int64)
     mask = np.asarray(mask).astype(np.int64)
 
     def acc_s(p):
         acc = float(np.mean((p == gt)[gt > 0]))
-        den = np.sum(np.maximum(np.abs(gt - 0), np.abs(gt - 3.0)) * (1 - (1 - (p > 0)) * (1 - gt > 0)))
+        den = np.sum(np.maximum(np.abs(gt - 0), np.abs(gt - 3.0)) * (1 - (1 - (p > 0)) * (np.uint8(1) - gt8 > 0)))
         return acc, float(1 - np.sum(np.abs(p - gt)) / den)
     acc, s = acc_s(p)
     pm = mask * p

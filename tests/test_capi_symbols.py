@@ -27,6 +27,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+    assert int(re.search(r'#define WSI_HIP_ABI_VERSION (\d+)', hdr).group(1)) == native.ABI_VERSION == lib.wsi_hip_abi_version()
 
 
 def test_pf_layout_helpers(lib):
@@ -93,3 +94,54 @@ def test_bad_arguments_return_einval(lib):
     assert lib.wsi_prepack_conv(None, None, None, None, None, 1e-5, 64, 64, 3, 2, None, None) == -22
     assert lib.wsi_conv3x3_bn_act(None, None, None, None, None, 1, 8, 8, 64, 64, 1, 1, 2, None) == -22
     assert lib.wsi_trunk_forward(None, None, None, 0, 0, 0, None, None, 1, 64, 64, None, 0, None, None, None, None) == -22
+
+
+def test_prepack_conv_mode3_fp6_planes(lib):
+    """Mode-3 weight pack (fp16 hi + MX-fp6 cross-term planes, include/wsi_hip.h): decode the 4 KB blocks on the host and check
+    them against the weights - frag 0/1 = fp16(w) in activation line order, frag 2/3 of lanes h=0 = fp6(hi / 2^(s-127)) and of
+    lanes h=1 = fp6((w - hi) / 2^(s-127)) in the field order the conv epilogue produces, every element within half an fp6 step
+    of its source and the block maximum inside fp6's top binade."""
+    rng = np.random.default_rng(3)
+    cout, cin, k = 32, 64, 3
+    w = (rng.standard_normal((cout, cin, k, k)) * rng.uniform(0.05, 3.0, (1, cin, 1, 1))).astype(np.float32)
+    nbytes = lib.wsi_prepack_conv_bytes(cout, cin, k, 3)
+    assert nbytes == (cout // 32) * (cin // 32) * 9 * 4096
+    out = np.zeros(nbytes, np.uint8)
+    bias = np.zeros(cout, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.wsi_prepack_conv(p(w), None, None, None, None, 1e-5, cout, cin, k, 3, p(out), p(bias)) == 0
+    assert not bias.any()
+    line_chan = lambda pos: 8 * ((pos & 15) >> 2) + 4 * (pos >> 4) + (pos & 3)          # common.h mx_line_chan
+    field_chan = lambda f: line_chan(16 * (f & 1) + (f >> 1))                           # common.h mx6_field_chan
+
+    def fp6(code):
+        e, m = (code >> 3) & 3, code & 7
+        v = (8 + m) * (0.125, 0.25, 0.5)[e - 1] if e else m * 0.125
+        return -v if code & 32 else v
+    blocks = out.reshape(cin // 32, 9, 4, 64, 16)
+    worst = 0.0
+    for l in range(cin // 32):
+        for t in range(9):
+            for r in (0, 5, 31):
+                wrow = w[r, 32 * l:32 * l + 32, t // 3, t % 3]
+                hi = wrow.astype(np.float16).astype(np.float32)
+                lo = wrow - hi
+                for h in (0, 1):
+                    lane = r + 32 * h
+                    f16 = np.concatenate([blocks[l, t, 0, lane].view(np.float16), blocks[l, t, 1, lane].view(np.float16)])
+                    pos = [8 * h + j for j in range(8)] + [16 + 8 * h + j for j in range(8)]
+                    assert np.array_equal(f16.astype(np.float32), hi[[line_chan(q) for q in pos]])
+                    words = np.concatenate([blocks[l, t, 2, lane].view(np.uint32), blocks[l, t, 3, lane].view(np.uint32)[:2]])
+                    sbyte = int(blocks[l, t, 3, lane].view(np.uint32)[2])
+                    bits = int.from_bytes(words.tobytes(), 'little')
+                    src = hi if h == 0 else lo
+                    amax = float(np.abs(src).max())
+                    assert 1 <= sbyte <= 254
+                    scale = 2.0 ** (sbyte - 127)
+                    assert 3.75 < amax / scale <= 7.75                                    # the top binade, never more than saturation
+                    for f in range(32):
+                        q = fp6((bits >> (6 * f)) & 63) * scale
+                        x = float(src[field_chan(f)])
+                        step = 0.5 if abs(x) / scale >= 4 else 0.25 if abs(x) / scale >= 2 else 0.125
+                        worst = max(worst, abs(q - x) / (step * scale))
+    assert worst <= 0.5 + 1e-6

@@ -70,6 +70,35 @@ def test_ring_upload_exact(ingest, h, w, ch, slots, slot_kb):
     ring.close()
 
 
+def test_ring_does_not_overtake_the_compute_stream(ingest):
+    """`out` may be a block the caching allocator recycled while kernels that still read its old contents are
+    queued on the compute stream; wsi_ring_acquire orders the ring's copy stream behind them.  A long kernel chain reads a
+    buffer, the buffer is freed, the upload lands in the recycled block: the chain's result must be of the OLD contents."""
+    h, w = 512, 1024
+    old = torch.full((h, w, 3), 7, dtype=torch.uint8, device='cuda:0')
+    ptr = old.data_ptr()
+    acc = torch.zeros((), dtype=torch.int64, device='cuda:0')
+    big = torch.ones((4096, 4096), device='cuda:0')
+    for _ in range(60):                                    # ~tens of ms of queued work in front of the readers
+        big = big @ big * 1e-4
+    for _ in range(20):
+        acc = acc + old.to(torch.int64).sum()              # queued readers of `old`
+    del old                                                # the block returns to the allocator (same stream: no sync)
+    ring = ingest.IngestRing(2, 1 << 20)
+    src = np.full((h, w, 3), 200, np.uint8)
+    out = ring.upload_level(lambda y0, rows, dst: dst.__setitem__(Ellipsis, src[y0:y0 + rows]), h, w, 3, 'cuda:0')
+    assert ring.device_index == 0
+    torch.cuda.synchronize()
+    if out.data_ptr() == ptr:                              # (the allocator did recycle the block: the hazard was live)
+        print('recycled block: hazard exercised')
+    assert int(acc.item()) == 20 * 7 * h * w * 3
+    assert np.array_equal(out.cpu().numpy(), src)
+    with pytest.raises(ValueError):
+        ring.upload_level(lambda *a: None, 4, 4, 3, 'cpu')
+    ring.close()
+    assert ingest.default_ring('cuda:0') is ingest.default_ring(torch.device('cuda', 0))
+
+
 def test_ring_rejects_bad_arguments(ingest):
     from wsi_segmentation_pipeline_amd import native
     ring = ingest.IngestRing(2, 4096)

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_PARITY = 1e-4      # relative to the tensor's max magnitude, bf16x2 split (3 MFMA passes)
 TOL_SPEED = 3e-2       # single-pass bf16
-TOL_MX = 4e-4          # fp16 main pass + MX-fp4 cross terms (mode 3), single layer
+TOL_MX = 1e-4          # fp16 main pass + MX-fp6 cross terms (mode 3), single layer (measured <= 3e-5)
 
 
 @pytest.fixture(scope='module')

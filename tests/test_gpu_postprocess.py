@@ -182,3 +182,20 @@ def test_contour_ordering_dropin(dev, golden_dir):
     assert np.abs(got - g['esp_sq9']).max() <= 1e-12
     t = co.evenly_spaced_points_on_a_contour(torch.from_numpy(g['contour']).to(dev), 8)
     assert t.is_cuda and np.abs(t.cpu().numpy() - g['esp8']).max() <= 1e-12
+
+
+def test_scores_uint8_wrap_weight_term(dev):
+    """wsi_score_counts against the literal uint8 NumPy evaluation of utils/eval.py:110-111 on a map with every (p, gt) pair in
+    {0..3}^2, in particular p == 0 against gt = 2, 3 (weight 0 in the reference: `1 - gt` wraps)."""
+    from wsi_segmentation_pipeline_amd import postprocess as PP
+    rng = np.random.default_rng(23)
+    p = rng.integers(0, 4, (64, 96)).astype(np.uint8)
+    gt = rng.integers(0, 4, (64, 96)).astype(np.uint8)
+    p[:16] = 0
+    gt[:16, :48], gt[:16, 48:] = 2, 3
+    mask = (rng.random(p.shape) < 0.8).astype(np.uint8)
+    got = PP.wsi_scores(torch.from_numpy(p).to(dev), torch.from_numpy(gt).to(dev), torch.from_numpy(mask).to(dev))
+    pi = p.astype(np.int64)                                                      # np.argmax result in the reference
+    lit = lambda q: float(1 - np.sum(np.abs(q - gt)) / np.sum(np.maximum(np.abs(gt - 0), np.abs(gt - 3.0)) * (1 - (1 - (q > 0)) * (1 - gt > 0))))
+    assert got['s'] == lit(pi) and got['s_masked'] == lit(mask.astype(np.int64) * pi)
+    assert got == P.wsi_scores(p, gt, mask)

@@ -26,7 +26,7 @@ def sd():
     return W.make_resnet18_state_dict(11)
 
 
-@pytest.mark.parametrize('planes,tol', [(2, 2e-4), (3, 1.5e-3)])
+@pytest.mark.parametrize('planes,tol', [(2, 2e-4), (3, 2e-4)])     # mx (fp6 cross terms) measures <= 7e-5 here: 3x headroom, not 8x
 def test_taps_vs_oracle_64(dev, sd, planes, tol):
     from wsi_segmentation_pipeline_amd.engine import TrunkEngine
     u8 = W.make_u8_patches(12, (2, 16, 3, 64, 64)).reshape(-1, 3, 64, 64)[:6]
@@ -139,7 +139,7 @@ def test_golden_cfg1_256(dev, sd, golden_dir):
 
 
 def test_golden_mode3_fp16_mx(dev, sd, golden_dir):
-    """Precision mode 3 (fp16 main pass + MX-fp4 cross terms) against the same reference goldens and the same contract."""
+    """Precision mode 3 (fp16 main pass + MX-fp6 cross terms) against the same reference goldens and the same contract."""
     for name in ('resnet18_bag64.npz', 'resnet18_cfg1_256.npz'):
         e1, e2 = _bag(dev, sd, name, 3, golden_dir)
         print('%s mode-3 max abs err: singles %.2e ensemble %.2e' % (name, e1, e2))

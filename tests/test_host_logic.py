@@ -299,3 +299,85 @@ def test_allreduce_map_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------ every collective at world 8 and 3, uneven and empty shards
+def _all_collectives_worker(rank, world, port, total, q):
+    """One process of `world`: tile-logit gather, bag-row gather, map all-reduce, span / probe-error reductions - with `total`
+    tiles / bags not divisible by the world (and total < world: ranks with nothing)."""
+    from wsi_segmentation_pipeline_amd import bags as B
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ok = {}
+    # (1) slide.gather_tile_logits: contiguous raster shares of `total` tiles
+    full = torch.arange(total * 4, dtype=torch.float32).view(total, 4) * 0.5 - 3
+    lo, hi = S.shard_range(total, rank, world)
+    ok['tiles'] = bool(torch.equal(S.gather_tile_logits(full[lo:hi].clone(), total, rank, world), full))
+    # (2) bags.gather_rows: greedy cost-balanced shares (non-contiguous index sets, empty ones when total < world)
+    costs = np.random.default_rng(7).lognormal(2, 1, total)
+    shards = B.shard_bags(costs, world)
+    mine = torch.as_tensor(np.asarray(shards[rank], np.int64))
+    ok['bags'] = bool(torch.equal(B.gather_rows(full[mine].clone(), shards, rank, world), full))
+    # (3) slide.allreduce_map: exact float64 sums of fp32 addends
+    g = torch.Generator().manual_seed(3)
+    tiles = torch.randn(total, 4, 8, 8, generator=g)
+    xy = torch.randint(0, 24, (total, 2), generator=g)
+    pred, ref = torch.zeros(4, 32, 32, dtype=torch.float64), torch.zeros(4, 32, 32, dtype=torch.float64)
+    for t in range(total):
+        x, y = int(xy[t, 0]), int(xy[t, 1])
+        ref[:, y:y + 8, x:x + 8] += tiles[t].double()
+        if lo <= t < hi:
+            pred[:, y:y + 8, x:x + 8] += tiles[t].double()
+    ok['map'] = bool(torch.equal(S.allreduce_map(pred), ref))
+    # (4) the reductions beside it: exponent span (None on a rank without tiles) and the precision probe's maximum
+    span = torch.tensor([120 + rank, 130 - rank], dtype=torch.int32) if hi > lo else None
+    owners = [r for r in range(world) if S.shard_range(total, r, world)[1] > S.shard_range(total, r, world)[0]]
+    sp = S.allreduce_span(span, torch.device('cpu')).tolist()
+    ok['span'] = sp == [120 + min(owners), 130 - min(owners)]
+    ok['max'] = S.allreduce_max(0.25 * rank if hi > lo else 0.0, torch.device('cpu'), world) == 0.25 * max(owners)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,total', [(8, 29), (8, 5), (3, 10), (3, 2)])
+def test_collectives_uneven_and_empty_shards(world, total):
+    """SURVEY.md 8e at the world sizes the driver scales to: 8 ranks (and 3) with totals that do not divide and totals below the
+    world size, so some ranks own nothing - every collective of the path must still return the single-rank result on all ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_all_collectives_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == list(range(world))
+    for r in range(world):
+        assert all(res[r].values()), (r, res[r])
+
+
+def test_bench_builds_eight_rank_environments(monkeypatch):
+    """`python bench.py --gpus 8` (the driver's scaling run when no launcher is used): eight children, each with its own
+    RANK / LOCAL_RANK, a shared 127.0.0.1 rendezvous and WORLD_SIZE 8; HSA_ENABLE_IPC_MODE_LEGACY stays 0 for RCCL."""
+    import bench
+    import sys as _sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        stub = os.path.join(d, 'stub.py')
+        with open(stub, 'w') as f:
+            f.write('import os, sys, json\n'
+                    'keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"]\n'
+                    'json.dump({k: os.environ.get(k) for k in keys} | {"argv": sys.argv[1:]},\n'
+                    '          open(os.path.join(os.path.dirname(__file__), "env%s.json" % os.environ["RANK"]), "w"))\n')
+        monkeypatch.setattr(bench, '__file__', stub)
+        monkeypatch.setattr(_sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1'])
+        assert bench.spawn_ranks(8) == 0
+        import json
+        envs = [json.load(open(os.path.join(d, 'env%d.json' % r))) for r in range(8)]
+    assert [int(e['RANK']) for e in envs] == list(range(8)) and [int(e['LOCAL_RANK']) for e in envs] == list(range(8))
+    assert {e['WORLD_SIZE'] for e in envs} == {'8'} and {e['MASTER_ADDR'] for e in envs} == {'127.0.0.1'}
+    assert len({e['MASTER_PORT'] for e in envs}) == 1 and {e['HSA_ENABLE_IPC_MODE_LEGACY'] for e in envs} == {'0'}
+    assert all(e['argv'] == ['--gpus', '8', '--steps', '2', '--warmup', '1'] for e in envs)

@@ -101,3 +101,21 @@ def test_tumor_bed_pipeline_and_scores():
     assert np.array_equal(poly[0], poly[-1]) and len(poly) >= 5
     pts = P.evenly_spaced_points_on_a_contour(poly, 32)
     assert pts.shape == (32, 2) and np.array_equal(pts[0], poly[0]) and np.allclose(pts[-1], poly[-1])
+
+
+def test_scores_follow_the_reference_uint8_arithmetic():
+    """utils/eval.py:110-111 evaluated literally on the dtypes the reference has - p = np.argmax (int64), gt = np.array(PIL image)
+    (uint8) - so `1 - gt > 0` wraps to gt != 1.  Pixels with p == 0 and gt in {2, 3} carry weight 0 in the denominator of `s`
+    (r02's int64 reading gave them weight 1)."""
+    rng = np.random.default_rng(11)
+    p = rng.integers(0, 4, (40, 50)).astype(np.int64)
+    gt = rng.integers(0, 4, (40, 50)).astype(np.uint8)
+    p[:10] = 0                                                           # plenty of p == 0 against gt = 2, 3
+    gt[:10, :25] = 2
+    gt[:10, 25:] = 3
+    lit = 1 - np.sum(np.abs(p - gt)) / np.sum(np.maximum(np.abs(gt - 0), np.abs(gt - 3.0)) * (1 - (1 - (p > 0)) * (1 - gt > 0)))
+    sc = P.wsi_scores(p, gt, np.ones_like(p))
+    assert sc['s'] == pytest.approx(float(lit), abs=0, rel=1e-15)
+    wrong = 1 - np.sum(np.abs(p - gt)) / np.sum(np.maximum(gt, np.abs(gt.astype(np.int64) - 3)) *
+                                                (1 - (1 - (p > 0)) * (1 - gt.astype(np.int64) > 0)))
+    assert abs(wrong - lit) > 1e-3                                       # the two readings really differ on this input

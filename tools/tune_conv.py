@@ -30,9 +30,12 @@ def main():
     ap.add_argument('--wcopies', type=int, default=1, help='study: replicate the packed weights N times (<= 16), workgroups spread over the copies')
     ap.add_argument('--scale', type=int, default=1, help='divide H,W by this (64x64 patches: 4)')
     ap.add_argument('--shapes', type=str, default='', help='comma list of indices into SHAPES')
+    ap.add_argument('--set-mode', type=int, default=-1, help='wsi_conv_set_mode value (A/B switches: include/wsi_hip.h)')
     ap.add_argument('--shape', type=str, default='', help='one explicit C,H,W shape (e.g. 64,256,256: the U-Net decoder\'s last level)')
     args = ap.parse_args()
     lib = native.load()
+    if args.set_mode >= 0:
+        native.check(lib.wsi_conv_set_mode(args.set_mode), 'wsi_conv_set_mode')
     dev = torch.device('cuda:0')
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(0)

@@ -8,9 +8,11 @@ the float64 map by wsi_stitch_add and the softmax/threshold/argmax/heat-map is o
 finished u8 images are copied back to be written as PNG.  There is no CPU fallback.
 
 Scope: the 'cls' path composes with the first-party backbone and is implemented
-end to end; predict_tumorbed(mode='seg') needs the third-party smp U-Net decoder (absent, parity-
-unpinned) and raises; predict_wsis runs any caller-supplied dense GPU module and does the
-accumulate / arg-max on the device."""
+end to end; predict_tumorbed(mode='seg') (the reference's default) drives ``model.decoder(model.encoder(x))`` of any GPU
+model - e.g. wsi_segmentation_pipeline_amd.unet.UNetSeg, the restatement of the third-party smp U-Net the reference
+uses, whose accuracy is therefore pinned to this repo's own specification of smp 0.0.x, not to the reference (absent
+package, no fixtures: "parity unpinned"); predict_wsis runs any caller-supplied dense GPU module and does the
+accumulate / resize / arg-max / tumour-bed post-process on the device (post-process oracles: parity unpinned too)."""
 import os
 
 import numpy as np
@@ -120,6 +122,7 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                 if world > 1:
                     lo, hi = S.shard_range(len(ds), rank, world)
                     my_it = it.shard(lo, hi)
+                span_lo, span_hi = None, None                 # exponent range of every addend: the exactness guard of the float64 sums
                 for batch_x, batch_y, batch_image in my_it:
                     pred_src = model.decoder(model.encoder(batch_image.to(dev)))
                     if args.scan_resize != 1:
@@ -129,15 +132,25 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                                          "scan at the map's level or set scan_resize (utils/eval.py:202-215)" % (tuple(pred_src.shape[2:]), dy, dx))
                     xy = np.stack((batch_x.numpy(), batch_y.numpy()), 1)
                     E.stitch_add_dense(pred, pred_src, torch.from_numpy(S.map_coords(xy, m)))
+                    sp = E.exponent_span(pred_src)
+                    span_lo = sp[0:1] if span_lo is None else torch.minimum(span_lo, sp[0:1])
+                    span_hi = sp[1:2] if span_hi is None else torch.maximum(span_hi, sp[1:2])
+                span = torch.cat((span_lo, span_hi)) if span_lo is not None else None
                 if world > 1:
+                    # (a deviation from SURVEY.md 8e, which sketches a band gather: tiles of a raster-order share overlap their
+                    # neighbours' bands when stride < tile, so the bands need a sum anyway; one all-reduce is that sum)
                     pred = S.allreduce_map(pred)
+                    span = S.allreduce_span(span, dev)
                 classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'seg', want_probs=False)
-                r = {'logits': None, 'pred': pred, 'classes': classes, 'heatmap': heat}
-            if r.get('exponent_span') is not None:             # the float64 stitch is exact (order-independent) inside this bound
-                over = (-(-ds.params.ph // ds.params.sh) + 1) * (-(-ds.params.pw // ds.params.sw) + 1)
-                E.check_stitch_exact(r['exponent_span'], over)
+                r = {'logits': None, 'pred': pred, 'classes': classes, 'heatmap': heat, 'exponent_span': span}
+            stitch_exact = None
+            if r.get('exponent_span') is not None:             # the float64 stitch is exact (order- and rank-independent) inside this
+                over = (-(-ds.params.ph // ds.params.sh) + 1) * (-(-ds.params.pw // ds.params.sw) + 1)      # bound; outside it the map
+                stitch_exact = E.stitch_is_exact(r['exponent_span'], over)                                   # is right to float64 rounding only
             heat = r['heatmap'].cpu().numpy()
-            results[key] = {'heatmap': heat, 'classes': r['classes'].cpu().numpy(), 'logits': r['logits']}
+            results[key] = {'heatmap': heat, 'classes': r['classes'].cpu().numpy(), 'logits': r['logits'],
+                            'precision': r.get('precision'),          # precision='auto': the mode this slide ran in, and why
+                            'stitch_exact': stitch_exact}
             if save and rank == 0:
                 _save_png(heat, '{}/{}_{}_heatmap.png'.format(out_dir, key, args.tile_stride_w))
                 thumb = np.asarray(scan.read_region((0, 0), ref_level, scan.level_dimensions[ref_level]).convert('RGB'))
@@ -263,7 +276,18 @@ def predict_regions(model, iterator, metadata, label_shape, class_probs=None, ra
     shards = B.shard_bags(np.full(R, 16.0), world)
     mine = iterator.shard(shards[rank]) if world > 1 else iterator
     with torch.no_grad():
-        parts = [model(images.to(dev))[1] for images, _ in mine]
+        parts = []
+        eng = model.hip_engine(dev) if world > 1 and hasattr(model, 'hip_engine') else None
+        probed = not hasattr(eng, 'probe_f32')                # precision='auto' over several ranks: ONE mode for every rank
+        for images, _ in mine:
+            images = images.to(dev)
+            if not probed:
+                eng.reset()
+                eng.decide(S.allreduce_max(eng.probe_f32(images.reshape(-1, *images.shape[2:])), dev, world), scope='regions')
+                probed = True
+            parts.append(model(images)[1])
+        if not probed:                                        # a rank without bags still takes part in the collective
+            eng.decide(S.allreduce_max(0.0, dev, world), scope='regions')
         num_classes = len(class_probs)
         local = torch.cat(parts) if parts else torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
         ens = B.gather_rows(local, shards, rank, world) if world > 1 else local

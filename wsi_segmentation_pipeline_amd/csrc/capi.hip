@@ -95,6 +95,8 @@ void* wsi_ring_host_slot_impl(wsi_ring* r, int slot);
 int wsi_ring_wait_slot_impl(wsi_ring* r, int slot);
 int wsi_ring_submit_impl(wsi_ring* r, int slot, int rows, int width, int channels, long long src_pitch, uint8_t* dst, long long dst_pitch);
 int wsi_ring_fence_impl(wsi_ring* r, hipStream_t compute);
+int wsi_ring_acquire_impl(wsi_ring* r, hipStream_t compute);
+int wsi_ring_device_impl(const wsi_ring* r);
 int wsi_ring_drain_impl(wsi_ring* r);
 void wsi_ring_destroy_impl(wsi_ring* r);
 int wsi_resample_plan_create_impl(wsi_resample_plan** out, int in_h, int in_w, int out_h, int out_w);
@@ -529,6 +531,8 @@ int wsi_ring_submit(wsi_ring* r, int slot, int rows, int width, int channels, lo
     return wsi_ring_submit_impl(r, slot, rows, width, channels, src_pitch, level_rows, level_pitch);
 }
 int wsi_ring_fence(wsi_ring* r, void* compute_stream) { return wsi_ring_fence_impl(r, (hipStream_t)compute_stream); }
+int wsi_ring_acquire(wsi_ring* r, void* compute_stream) { return wsi_ring_acquire_impl(r, (hipStream_t)compute_stream); }
+int wsi_ring_device(const wsi_ring* r) { return wsi_ring_device_impl(r); }
 int wsi_ring_drain(wsi_ring* r) { return wsi_ring_drain_impl(r); }
 void wsi_ring_destroy(wsi_ring* r) { wsi_ring_destroy_impl(r); }
 int wsi_resample_plan_create(wsi_resample_plan** out, int in_h, int in_w, int out_h, int out_w) {

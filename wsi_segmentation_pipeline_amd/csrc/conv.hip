@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     }
     if constexpr (PLANES == 3) {
         if (a.resid) __syncthreads();                         // every wave is done reading pixel fragments: slab memory becomes
-        conv_tail_mx<1, MT, RESID_NBUF>(a, acc, qs, valid, ntile, lane, smem + wave * (RESID_NBUF * 4096));   // the waves' residual staging
+        conv_tail_mx<1, MT, RESID_NBUF>(a, acc, qs, valid, ntile, lane, smem + wave * (RESID_NBUF * 4096), slab0);   // the waves' residual staging
     } else {
         char* scratch = nullptr;
         if (PLANES == 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     }
 
     auto xload = [&](bf16x8(&x)[4], int Pl) {
+        asm volatile("" : "+v"(Pl));                          // opaque: each step's address arithmetic stays at the step (no hoisting, no spills)
         const int base = lds_xbase(Pl, h);
 #pragma unroll
         for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     }
     if constexpr (PLANES == 3) {
         if (a.resid) __syncthreads();                         // weight stages + slab become the waves' residual staging (NBUF tiles each)
-        conv_tail_mx<NT, MT, RESID_NBUF>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096));
+        conv_tail_mx<NT, MT, RESID_NBUF>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096), slab0);
     } else {
         char* scratch = nullptr;
         if (PLANES == 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) {    // slab memory becomes the waves' residual staging (epilogues)
@@ -816,7 +817,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                     const int sh = SH1[ph][k] + SHP[ph][k] * P;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const int Pl = qs[mt] - q0 + sh;
+                        int ql = qs[mt] - q0;
+                        asm volatile("" : "+v"(ql));           // opaque: the address arithmetic of every (line, step) is done HERE (hoisted
+                        const int Pl = ql + sh;                // out of the line loop it costs ~70 registers and spills into the loop)
                         const int base = lds_xbase(Pl, h);
 #pragma unroll
                         for (int f = 0; f < 4; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
@@ -970,6 +973,8 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     // product build: only the tuned configurations are instantiated (cfg 30 / 31: slab3 for 128-multiple / 64-channel outputs)
     if (cfg == 30) return planes == 3 ? launch_slab3<4, 1, 4, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 1, 4, 2, 2, true>(a, st) : launch_slab3<4, 1, 4, 1, 2, true>(a, st);
     if (cfg == 31) return planes == 3 ? launch_slab3<4, 2, 2, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 2, 2, 2, 2, true>(a, st) : launch_slab3<4, 2, 2, 1, 2, true>(a, st);
+    // cfg 38: cfg 31 held to 168 registers = three waves per SIMD, three workgroups per CU (r03 A/B on layer 1)
+    if (cfg == 38) return planes == 3 ? launch_slab3<4, 2, 2, 3, 3, true>(a, st) : WSI_EINVAL;
     // cfg 39: 512 px x 64 couts (4 x 2 waves) for 64-channel layers on maps wider than 128 (the U-Net decoder's last level): a
     // 256-pixel tile of a 256-wide map is ONE row under a three-row slab; two rows per tile cut the halo from 3x to 2x
     if (cfg == 39) return planes == 3 ? launch_slab3<4, 4, 2, 3, 1, true>(a, st) : planes == 2 ? launch_slab3<4, 4, 2, 2, 1, true>(a, st) : launch_slab3<4, 4, 2, 1, 1, true>(a, st);
@@ -981,19 +986,22 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
 int g_wide_min_c = 128;                                  // channel count from which the wide kernel (cfg 60) is the default
                                                          // (r01: 3-8 % faster than cfg 30 on layers 2-4; A/B via wsi_conv_set_mode)
 static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {           // r01 / r02 tunes: profiles/r0*_tune_conv*.log
-    // 256-multiple outputs (layers 3-4): the 8-wave ping-pong kernel (r02: +1...4 % over the wide kernel in mx, +4...7 % over
-    // slab3 in single-pass bf16; bit-identical).  It needs two slabs in LDS: maps wider than 33 fall back.
     if (a.go.C % 64) return fallback ? 91 : 90;              // 32 output channels
     // maps up to 4 x 4 (64 x 64 crops of the region-bag path: 25-56 % of a slab is padding): the small slab3 tiles keep four
     // workgroups per CU where the wide / ping-pong slabs leave one (r02 tune, n = 32000: 1.13 vs 1.28 ms at 4 x 4, 0.94 vs 1.15 at 2 x 2)
     if (a.gi.W <= 4 && a.go.C % 128 == 0 && planes == 3) return 30;
-    if (!fallback && planes != 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
+    // r03 (fp6 line format, residual through the matrix pipe): in mx the 4-wave wide kernel - two workgroups per CU, so one
+    // workgroup's tail runs beside the other's main loop - ties the ping-pong kernel without a residual and beats it by 2-3 %
+    // with one (profiles/r03_tune_conv_mx.log); the ping-pong kernel stays the default of the single-pass bf16 mode.
+    // (256-multiple outputs, layers 3-4; +4...7 % over slab3 there; it needs two slabs in LDS: maps wider than 33 fall back)
+    if (!fallback && planes == 1 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
     // parity mode (r02 tune, n = 2000): the ping-pong kernel in its 256 px x 128 couts shape on layers 3-4 (1.48 / 1.38 vs 1.55 / 1.43 ms
     // for the wide kernel), slab3 on layer 2 (1.69 vs 1.78 ms)
     if (!fallback && planes == 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 83;
     if (planes == 2 && a.go.C == 128 && a.gi.W > 8 && g_wide_min_c <= 128) return 30;
     if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
+    if (a.go.C % 128 != 0 && planes == 3 && !fallback) return 38;         // r03 tune, layer 1: 1.416 / 1.619 ms vs 1.435 / 1.666 (cfg 31), n = 2000
     return a.go.C % 128 == 0 ? 30 : 31;
 }
 

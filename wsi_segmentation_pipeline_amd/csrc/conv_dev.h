@@ -34,6 +34,19 @@ static __device__ __forceinline__ void resid_tile_dma(const void* resid, int q_o
     }
 }
 
+// Buffer-addressed form for the mode-3 tail: `rs` = the residual tensor from the first pixel of the workgroup's slab on,
+// q_rel = this lane's pixel relative to it (both tensors of a stride-1 conv share one geometry), so the per-lane offset
+// is 32-bit arithmetic and the channel-tile offset is scalar.
+static __device__ __forceinline__ void resid_tile_dma_buf(__amdgpu_buffer_rsrc_t rs, int q_rel, int pixstride, int line_off, int lane, char* dst) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pp = 8 * j + (lane >> 3);
+        const int q = __shfl(q_rel, pp);
+        const int sl = (lane & 7) ^ ((pp >> 1) & 7);
+        dma16_buf(rs, dst + j * 1024, q * pixstride + sl * 16, line_off);
+    }
+}
+
 template <int MT, int PLANES>
 static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                        const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
@@ -214,7 +227,7 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
 // stores the compiler places between the DMAs cannot break a counted wait.
 template <int NT, int MT, int NBUF>
 static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&acc)[NT][MT], const int (&qs)[MT], const bool (&valid)[MT],
-                                                    int ntile0, int lane, char* scratch) {
+                                                    int ntile0, int lane, char* scratch, int slab0) {
     constexpr int T = NT * MT;
     static_assert(MT % NBUF == 0 || NBUF % MT == 0, "a batch is part of one channel tile or whole channel tiles");
     if (!a.resid) {
@@ -223,7 +236,11 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
         return;
     }
     const int h = lane >> 5, l31 = lane & 31;
-    const size_t pixstride = (size_t)a.go.C * 4;
+    const int pixstride = a.go.C * 4;
+    // the residual from the slab's first pixel on (slab0 = the workgroup's first input pixel = a pixel of the residual too)
+    const size_t rbase = (size_t)slab0 * pixstride, rbytes = (size_t)pf_alloc_pixels(a.go.N, a.go.H, a.go.W) * pixstride;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.resid + rbase), 0,
+                                                                          (int)min(rbytes - rbase, (size_t)0x7fffffff), 0x00020000);
     bf16x8 iw[4];
     {
         const int p = mx_line_pos(l31), f0 = mx6_field_of_pos(p);
@@ -246,7 +263,9 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
     }
     auto rdma = [&](int k) {
         const int nt = k / MT, mt = k % MT;
-        resid_tile_dma(a.resid, valid[mt] ? qs[mt] : a.go.G, pixstride, (size_t)(ntile0 + nt) * 128, lane, scratch + (k % NBUF) * 4096);
+        int qr = qs[mt] - slab0;                                // (rows past the end repeat the tile's last pixel: a real one)
+        asm volatile("" : "+v"(qr));                            // opaque: offsets are rebuilt per batch, not kept alive across the encodes
+        resid_tile_dma_buf(rrs, qr, pixstride, (ntile0 + nt) * 128, lane, scratch + (k % NBUF) * 4096);
     };
     const int xb = l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
 #pragma unroll

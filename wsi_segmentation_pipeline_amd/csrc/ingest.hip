@@ -97,6 +97,16 @@ int wsi_ring_fence_impl(wsi_ring* r, hipStream_t compute) {
     return WSI_OK;
 }
 
+// The copy stream writes destination memory the caller allocated on its compute stream: a caching allocator may hand out a
+// block whose last readers (kernels of the previous slide) are still queued THERE.  acquire orders the ring's copies after
+// everything enqueued on `compute` so far (an event wait, no host block).
+int wsi_ring_acquire_impl(wsi_ring* r, hipStream_t compute) {
+    if (!r) return WSI_EINVAL;
+    if (hipEventRecord(r->fence, compute) != hipSuccess || hipStreamWaitEvent(r->copy, r->fence, 0) != hipSuccess) return WSI_EFAULT;
+    return WSI_OK;
+}
+int wsi_ring_device_impl(const wsi_ring* r) { return r ? r->device : -1; }
+
 int wsi_ring_drain_impl(wsi_ring* r) {
     if (!r) return WSI_EINVAL;
     if (hipStreamSynchronize(r->copy) != hipSuccess) return WSI_EFAULT;

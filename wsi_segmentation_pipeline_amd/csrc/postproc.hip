@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const uint8_t* a, const
 
 // The integer sums behind utils/eval.py:107-121 for a class map p (optionally times a 0/1 mask), ground truth gt:
 //   out[0] = #(gt > 0)            out[1] = #(p == gt and gt > 0)        out[2] = sum |p - gt|
-//   out[3] = sum max(gt, |gt - 3|) * (1 - (1 - (p > 0)) * ((1 - gt) > 0))  (the reference's precedence, kept)
+//   out[3] = sum max(gt, |gt - 3|) * (1 - (1 - (p > 0)) * (gt != 1))
+//            the reference writes `(1 - gt > 0)` = `(1 - gt) > 0` with gt the uint8 array of a PIL image, so 1 - gt WRAPS
+//            (0 -> 1, 1 -> 0, 2 -> 255, 3 -> 254) and the factor is gt != 1, not gt == 0 (r02 had the int64 reading)
 //   out[4] = #((p > 0) and (gt > 0))   out[5] = #((p > 0) or (gt > 0))
 __global__ __launch_bounds__(256) void score_counts_kernel(const uint8_t* p, const uint8_t* gt, const uint8_t* mask, long long n,
                                                            unsigned long long* out) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void score_counts_kernel(const uint8_t* p, con
         s[1] += (pv == g) && g > 0;
         s[2] += (unsigned long long)abs(pv - g);
         const int mx = max(g, abs(g - 3));
-        s[3] += (unsigned long long)(mx * (1 - (1 - (pv > 0)) * ((1 - g) > 0)));
+        s[3] += (unsigned long long)(mx * (1 - (1 - (pv > 0)) * (g != 1)));
         s[4] += (pv > 0) && (g > 0);
         s[5] += (pv > 0) || (g > 0);
     }

@@ -172,8 +172,8 @@ int wsi_paint_dispatch(const long long* idx, const int* region_of, long long n, 
 
 int wsi_exponent_span_dispatch(const float* v, long long n, int* out2, hipStream_t st) {
     if (n <= 0) return WSI_EINVAL;
-    const int init[2] = {255, 0};
-    if (hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return WSI_EFAULT;
+    // {255, 0} without a host buffer (a pageable H2D copy would block the host on the stream): zero both ints, then one 0xff byte
+    if (hipMemsetAsync(out2, 0, 2 * sizeof(int), st) != hipSuccess || hipMemsetAsync(out2, 0xff, 1, st) != hipSuccess) return WSI_EFAULT;
     hipLaunchKernelGGL(exponent_span_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(256), 0, st, v, n, out2);
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }

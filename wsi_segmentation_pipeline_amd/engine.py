@@ -11,8 +11,8 @@ import torch
 from . import native
 
 BN_EPS = 1e-5                                   # nn.BatchNorm2d default (reference resnets_shift.py:117)
-PARITY, SPEED, MX = 2, 1, 3                     # planes: bf16x2 split (3 passes) / single bf16 / fp16 + MX-fp4 cross terms
-AUTO = 'auto'                                   # AutoTrunkEngine: mx unless a two-mode probe of the first batch says parity
+PARITY, SPEED, MX = 2, 1, 3                     # planes: bf16x2 split (3 passes) / single bf16 / fp16 + MX-fp6 cross terms
+AUTO = 'auto'                                   # AutoTrunkEngine: mx unless a stratified two-mode probe of the slide says parity
 
 
 def _np_ptr(a):
@@ -61,7 +61,7 @@ class TrunkEngine:
         if self.device.type != 'cuda':
             raise RuntimeError('TrunkEngine needs a GPU device, got %s' % device)
         if planes not in (1, 2, 3):
-            raise ValueError('planes must be 1 (speed), 2 (parity, bf16 split) or 3 (parity, fp16 + MX-fp4)')
+            raise ValueError('planes must be 1 (speed), 2 (parity, bf16 split) or 3 (mx, fp16 + MX-fp6)')
         self.planes = planes
         # images per trunk call; None = sized so that every kernel fills the chip several times over (2000 patches of 256x256,
         # scaled by patch area; the workspace is ~8.3 MB per 256x256 patch: 17 GB of the 288 GB)
@@ -255,16 +255,19 @@ class TrunkEngine:
 
 class AutoTrunkEngine:
     """TrunkEngine that picks its precision mode per checkpoint AND data, so a caller cannot silently leave the 1e-3 logit
-    contract (BASELINE.json north_star).  mx (fp16 + MX-fp4 cross terms) is ~1.35x faster than parity (bf16x2 split) but
-    its logit error scales with the logit magnitude (2-5e-4 at |logit| ~ 1.5-5, ~4e-3 at |logit| ~ 16: measured against
-    reference goldens, tests/test_gpu_margin.py); parity is 10-20x more accurate.  So:
+    contract (BASELINE.json north_star).  mx (fp16 + MX-fp6 cross terms) is ~1.35x faster than parity (bf16x2 split); both
+    hold the contract on every reference-generated weight / input family (tests/test_gpu_margin.py: mx <= 6.3e-4, parity
+    <= 4.0e-4 at |logit| = 16), but every finite-precision error grows with the logit magnitude, so the choice is guarded:
       * at load: the folded weights must be representable (finite, inside the fp16 range) or mx is refused outright;
-      * on the first batch: up to `probe` images run in BOTH modes; |mx - parity| (= mx's own error to ~10 %) on the head
-        logits - or, without a head, on the pooled features relative to their size - decides: mx if <= `tol`
-        (default 4e-4: 2.5x inside the contract), parity otherwise.  The decision and the measured value are kept in
-        `.report` and the probe is repeated when the head changes."""
+      * per slide (forward_tiles) / per head (forward_f32): `probe` images - a STRATIFIED sample over the whole tile list,
+        never its first tiles: a slide's first raster tiles are one corner of the tissue - run in BOTH modes; |mx - parity|
+        on the head logits (without a head: on the pooled features relative to their size) decides: mx if <= `tol`
+        (default 5e-4: half the contract), parity otherwise;
+      * with several ranks the decision must be ONE decision: callers that shard a slide (slide.infer_slide_cls) take the
+        local `probe_tiles` error, all-reduce its maximum and hand it to `decide`, so no rank mixes modes into a gathered map.
+    The decision and the measured value are kept in `.report` (utils.eval.predict_tumorbed returns it per slide)."""
 
-    def __init__(self, state_dict, device, head=None, tol=4e-4, probe=32, **kw):
+    def __init__(self, state_dict, device, head=None, tol=5e-4, probe=32, **kw):
         self._kw = dict(kw)
         self._sd, self._dev, self.tol, self.probe = state_dict, device, float(tol), int(probe)
         self.report = {'mode': None, 'reason': 'not probed yet', 'probe_error': None}
@@ -276,6 +279,7 @@ class AutoTrunkEngine:
         else:
             self.report = {'mode': 'parity', 'reason': reason, 'probe_error': None}
         self._chosen = None if self._mx is not None else self._par
+        self._slide_key = None
 
     @staticmethod
     def _static_check(sd):
@@ -315,31 +319,62 @@ class AutoTrunkEngine:
     def linear(self, *a, **k):
         return self._par.linear(*a, **k)
 
-    def _decide(self, run):
-        """run(engine) -> (feat, logits, fmap) on the probe images, feat and logits requested where possible."""
-        if self._chosen is not None:
-            return
+    def reset(self):
+        """Forget the decision: the next forward (or probe_tiles / decide pair) probes again."""
+        if self._mx is not None:
+            self._chosen, self._slide_key = None, None
+
+    def _stratified(self, total):
+        n = min(self.probe, int(total))
+        return torch.linspace(0, max(int(total) - 1, 0), n, device=self._dev).round().long()
+
+    def _probe(self, run):
+        """run(engine) -> (feat, logits, fmap) on the probe images.  Returns (error, what, n): |mx - parity| as described above."""
         fm, lm, _ = run(self._mx)
         fp, lp, _ = run(self._par)
         if lm is not None:
-            err, what = float((lm - lp).abs().max()), 'max |logit_mx - logit_parity|'
-        else:
-            err, what = float((fm - fp).abs().max() / fp.abs().max().clamp_min(1e-30)) * 2.0, '2 x max |feat_mx - feat_parity| / max |feat|'
-        ok = np.isfinite(err) and err <= self.tol
+            return float((lm - lp).abs().max()), 'max |logit_mx - logit_parity|', int(lp.shape[0])
+        return (float((fm - fp).abs().max() / fp.abs().max().clamp_min(1e-30)) * 2.0, '2 x max |feat_mx - feat_parity| / max |feat|',
+                int(fp.shape[0]))
+
+    def probe_tiles(self, slide_u8, tile_xy, ph, pw):
+        """Local probe error of mx on a stratified sample of `tile_xy` (0.0 without tiles or without an mx engine); the caller
+        all-reduces the maximum over its ranks and calls decide()."""
+        if self._mx is None or int(tile_xy.shape[0]) == 0:
+            return 0.0
+        xy = tile_xy[self._stratified(tile_xy.shape[0])].contiguous()
+        err, self._what, self._n = self._probe(lambda e: e.forward_tiles(slide_u8, xy, ph, pw, feat=True, logits=bool(e.head_k)))
+        return err
+
+    def probe_f32(self, x):
+        """probe_tiles for the tensor-input path: local probe error on a stratified sample of the batch x (N, 3, H, W)."""
+        if self._mx is None or int(x.shape[0]) == 0:
+            return 0.0
+        idx = self._stratified(x.shape[0])
+        err, self._what, self._n = self._probe(lambda e: e.forward_f32(x[idx], feat=True, logits=bool(e.head_k)))
+        return err
+
+    def decide(self, err, scope='slide'):
+        """Fix the mode for the coming forwards from a (rank-global) probe error."""
+        if self._mx is None:
+            return
+        ok = bool(np.isfinite(err)) and err <= self.tol
         self._chosen = self._mx if ok else self._par
-        self.report = {'mode': 'mx' if ok else 'parity', 'probe_error': err,
-                       'reason': '%s = %.2e %s tol %.1e on %d probe images' % (what, err, '<=' if ok else '>', self.tol, int(fp.shape[0]))}
+        self.report = {'mode': 'mx' if ok else 'parity', 'probe_error': float(err), 'scope': scope,
+                       'reason': '%s = %.2e %s tol %.1e on %d stratified probe images' %
+                                 (getattr(self, '_what', 'probe error'), err, '<=' if ok else '>', self.tol, getattr(self, '_n', 0))}
 
     def forward_f32(self, x, feat=False, logits=False, fmap=False, tap=None):
         if self._chosen is None:
-            n = min(self.probe, x.shape[0])
-            self._decide(lambda e: e.forward_f32(x[:n], feat=True, logits=bool(e.head_k)))
+            self.decide(self.probe_f32(x), scope='head')
         return self._chosen.forward_f32(x, feat=feat, logits=logits, fmap=fmap, tap=tap)
 
     def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
-        if self._chosen is None:
-            n = min(self.probe, tile_xy.shape[0])
-            self._decide(lambda e: e.forward_tiles(slide_u8, tile_xy[:n], ph, pw, feat=True, logits=bool(e.head_k)))
+        # one decision per slide: a new slide tensor (or a reset) probes again; chunks of the same slide reuse the decision
+        key = (int(slide_u8.data_ptr()), tuple(slide_u8.shape))
+        if self._mx is not None and (self._chosen is None or (self._slide_key is not None and key != self._slide_key)):
+            self.decide(self.probe_tiles(slide_u8, tile_xy, ph, pw))
+        self._slide_key = key
         return self._chosen.forward_tiles(slide_u8, tile_xy, ph, pw, feat=feat, logits=logits, fmap=fmap, tap=tap)
 
 
@@ -441,10 +476,18 @@ def exponent_span(values):
     return out
 
 
+def stitch_is_exact(span, addends_per_pixel):
+    """True when float64 sums of the guarded fp32 values are provably exact, hence independent of the order of the tiles and
+    of how ranks split them: exponent span + log2(addends per pixel) <= 29 (a 53-bit significand holds every partial sum).
+    Outside the bound the map is still correct to float64 rounding (<= 2^-52 relative per addition), just not bit-reproducible."""
+    lo, hi = (int(v) for v in span.cpu())
+    return not (hi >= lo and (hi - lo) + int(np.ceil(np.log2(max(1, addends_per_pixel)))) > 29)
+
+
 def check_stitch_exact(span, addends_per_pixel):
     """Raise if float64 sums of the guarded fp32 values could be inexact (order-dependent): see wsi_exponent_span."""
     lo, hi = (int(v) for v in span.cpu())
-    if hi >= lo and (hi - lo) + int(np.ceil(np.log2(max(1, addends_per_pixel)))) > 29:
+    if not stitch_is_exact(span, addends_per_pixel):
         raise RuntimeError('stitch: the per-tile values span 2^%d with up to %d addends per pixel: float64 sums are no longer exact, '
                            'so the accumulated map would depend on the order of the tiles' % (hi - lo, addends_per_pixel))
 

@@ -23,6 +23,7 @@ class IngestRing:
         h = C.c_void_p()
         native.check(self.lib.wsi_ring_create(C.byref(h), self.slots, self.slot_bytes), 'wsi_ring_create')
         self._h = h
+        self.device_index = int(self.lib.wsi_ring_device(h))          # staging buffers + copy stream live on this device
 
     def close(self):
         if self._h is not None:
@@ -47,10 +48,19 @@ class IngestRing:
         """Fill an (h, w, 3) uint8 device level from `read_band(y0, rows, dst)` (dst: (rows, w, channels) pinned uint8 view the
         reader fills; called on worker threads, one band each).  Decode of band i+1.. overlaps the copy of band i.
         Returns the device tensor; with fence=True the current compute stream is ordered after the last copy."""
-        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        dev = torch.device('cuda', self.device_index) if device is None else torch.device(device)
+        if dev.type != 'cuda' or (dev.index if dev.index is not None else torch.cuda.current_device()) != self.device_index:
+            raise ValueError('this ring stages for cuda:%d, not %s (one ring per device: default_ring(device))' % (self.device_index, dev))
+        dev = torch.device('cuda', self.device_index)
         if out is None:
             out = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
         _require_gpu(out, 'level')
+        if out.device.index != self.device_index:
+            raise ValueError('out lives on %s, the ring on cuda:%d' % (out.device, self.device_index))
+        # `out` may be a block the caching allocator just recycled on the compute stream: the ring's copies must not overtake the
+        # kernels still queued there that read its previous contents
+        with torch.cuda.device(dev):
+            native.check(self.lib.wsi_ring_acquire(self._h, _stream()), 'wsi_ring_acquire')
         if tuple(out.shape) != (h, w, 3) or not out.is_contiguous():
             raise ValueError('out must be a contiguous (h, w, 3) uint8 tensor')
         row_bytes = w * channels
@@ -82,27 +92,32 @@ class IngestRing:
         finally:
             pool.shutdown(wait=True)
         if fence:
-            native.check(self.lib.wsi_ring_fence(self._h, _stream()), 'wsi_ring_fence')
+            with torch.cuda.device(dev):
+                native.check(self.lib.wsi_ring_fence(self._h, _stream()), 'wsi_ring_fence')
         return out
 
     def drain(self):
         native.check(self.lib.wsi_ring_drain(self._h), 'wsi_ring_drain')
 
 
-_default_ring = None
+_default_rings = {}
 
 
-def default_ring():
-    global _default_ring
-    if _default_ring is None:
-        _default_ring = IngestRing()
-    return _default_ring
+def default_ring(device=None):
+    """The process's ring of `device` (default: the current one) - one per device: staging buffers and copy stream are device
+    resources."""
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _default_rings:
+        with torch.cuda.device(idx):
+            _default_rings[idx] = IngestRing()
+    return _default_rings[idx]
 
 
 def level_from_slide(scan, level, device, ring=None):
     """One pyramid level of an OpenSlide-like object (`read_region((x0, y0_level0), level, (w, rows))` -> RGBA PIL image) into
     HBM through the ring."""
-    ring = ring or default_ring()
+    ring = ring or default_ring(device)
     w, h = scan.level_dimensions[level]
     ds = scan.level_downsamples[level]
 
@@ -114,7 +129,7 @@ def level_from_slide(scan, level, device, ring=None):
 
 def level_from_array(arr, device, ring=None):
     """Host ndarray / memmap (h, w, 3|4) uint8 -> HBM through the ring (the band copy into the pinned slot is the "decode")."""
-    ring = ring or default_ring()
+    ring = ring or default_ring(device)
     h, w, ch = arr.shape
     if ch == 4 and (w * 4) % 4 == 0:
         def read_band(y0, rows, dst):

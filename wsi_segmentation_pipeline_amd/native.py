@@ -78,6 +78,8 @@ SIGNATURES = {
     'wsi_ring_wait_slot': (_i, [_vp, _i]),
     'wsi_ring_submit': (_i, [_vp, _i, _i, _i, _i, _ll, _vp, _ll]),
     'wsi_ring_fence': (_i, [_vp, _vp]),
+    'wsi_ring_acquire': (_i, [_vp, _vp]),
+    'wsi_ring_device': (_i, [_vp]),
     'wsi_ring_drain': (_i, [_vp]),
     'wsi_ring_destroy': (None, [_vp]),
     'wsi_resample_plan_create': (_i, [_vp, _i, _i, _i, _i]),
@@ -125,6 +127,9 @@ def build(verbose=False):
     return LIB_PATH
 
 
+ABI_VERSION = 3                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -138,7 +143,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lost a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.wsi_hip_abi_version() != 2:
+    if lib.wsi_hip_abi_version() != ABI_VERSION:
         raise RuntimeError('libwsi_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -51,13 +51,13 @@ class ArraySlide:
         if t is None:
             l = self.levels[level]
             if isinstance(l, torch.Tensor):
-                t = l.to(device)
+                t = l.to(device)[..., :3]
             elif l.nbytes >= (32 << 20):                       # host arrays / memmaps: pinned ring, copies overlap the band reads
                 from . import ingest
                 t = ingest.level_from_array(l, device)
             else:
-                t = torch.from_numpy(np.ascontiguousarray(l)).to(device)
-            self._dev[key] = t.contiguous()
+                t = torch.from_numpy(np.ascontiguousarray(l[..., :3])).to(device)
+            self._dev[key] = t.contiguous()                    # always (H, W, 3): an alpha plane is dropped on every path
         return self._dev[key]
 
     def close(self):
@@ -128,7 +128,12 @@ def tile_grid_device(iw, ih, ph, pw, sh, sw, mask=None, m=1.0, thresh=0.05, devi
     mk = None
     if mask is not None:
         mk = (mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask))).to(dev)
-        mk = (mk != 0).to(torch.uint8).contiguous()
+        mk = mk != 0
+        if mk.dim() == 3:                                      # colour mask images: nonzero in any channel (tile_grid's .any(-1))
+            mk = mk.any(-1)
+        if mk.dim() != 2:
+            raise ValueError('mask must be (MH, MW) or (MH, MW, channels), got %s' % (tuple(mk.shape),))
+        mk = mk.to(torch.uint8).contiguous()
     out = torch.empty((n, 2), dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     scratch = torch.empty(lib.wsi_tile_grid_scratch_bytes(n), dtype=torch.uint8, device=dev)
@@ -181,6 +186,27 @@ def gather_tile_logits(local_logits, total, rank, world):
         lo, hi = shard_range(total, r, world)
         parts.append(out[r * chunk:r * chunk + (hi - lo)])
     return torch.cat(parts, 0)
+
+
+def allreduce_max(value, dev, world):
+    """Maximum of a host scalar over the ranks (world == 1: the value itself).  RCCL needs a device buffer, gloo a host one."""
+    import torch.distributed as dist
+    if world == 1 and not _collective_forced():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_span(span, dev):
+    """Exponent span (2 int32: smallest, largest biased exponent; None = this rank added nothing) over the ranks."""
+    import torch.distributed as dist
+    on = dev if dist.get_backend() == 'nccl' else 'cpu'
+    lo = (span[0:1] if span is not None else torch.full((1,), 255, dtype=torch.int32)).to(on)
+    hi = (span[1:2] if span is not None else torch.zeros(1, dtype=torch.int32)).to(on)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return torch.cat((lo, hi)).to(dev)
 
 
 def allreduce_map(pred):
@@ -320,6 +346,11 @@ def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classe
     if local_xy is not None and len(local_xy) != hi - lo:
         raise ValueError('local_xy must list this rank\'s %d tiles' % (hi - lo))
     xy_dev = _upload(tile_xy[lo:hi] if local_xy is None else local_xy, torch.int32, dev)
+    precision = None
+    if hasattr(eng, 'probe_tiles'):
+        # precision='auto': ONE mode per slide for every rank - stratified probe of this rank's shard, maximum over the ranks
+        eng.decide(allreduce_max(eng.probe_tiles(slide_level_dev, xy_dev, ph, pw), dev, world))
+        precision = dict(eng.report)
     if hi > lo:
         _, logits, _ = eng.forward_tiles(slide_level_dev, xy_dev, ph, pw, logits=True)
     else:
@@ -332,4 +363,5 @@ def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classe
         E.stitch_add(pred, logits, mxy, int(m * ph), int(m * pw))
         span = E.exponent_span(logits)                    # guard of the float64 atomics (checked by the caller: no sync here)
     classes, probs, heat = E.softmax_threshold_argmax(pred, class_probs, mask_dev, 'cls', want_probs)
-    return {'logits': logits, 'pred': pred, 'classes': classes, 'probs': probs, 'heatmap': heat, 'exponent_span': span}
+    return {'logits': logits, 'pred': pred, 'classes': classes, 'probs': probs, 'heatmap': heat, 'exponent_span': span,
+            'precision': precision}
