@@ -234,6 +234,16 @@ int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, do
 size_t wsi_connected_components_scratch_bytes(int h, int w);
 int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream);
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream);
+/* slic.py:43 skimage.segmentation.slic(img_as_float(rgb), n_segments, compactness, sigma, enforce_connectivity=False) on a 2-D RGB
+ * thumbnail, as an own deterministic specification of the published algorithm (skimage is absent: parity unpinned;
+ * oracle/proposals_oracle.py slic_labels): Gaussian filter with the caller's 2 radius + 1 float64 weights (scipy.ndimage order,
+ * reflect; radius 0 = none) -> rgb2lab / compactness in 2^-20 fixed point -> `iters` rounds of windowed nearest-centre assignment
+ * (ties to the lower centre) + exact-integer mean update.  segments: k x {cy, cx, c0, c1, c2, alive} float64, in: skimage's
+ * regular grid (colour 0, alive 1), out: the final centres; step_y / step_x: the grid steps, step = their maximum.
+ * labels_out (h, w) int32 in [0, k).  scratch: wsi_slic_scratch_bytes(h, w, k); k <= 2048. */
+size_t wsi_slic_scratch_bytes(int h, int w, int k);
+int wsi_slic(const uint8_t* rgb, int h, int w, const double* gauss_weights, int radius, double* segments, int k, int step_y, int step_x,
+             double step, double compactness, int iters, int* labels_out, void* scratch, void* stream);
 /* tile list of the sliding-window path on the device (utils/dataset.py:143-166): candidates in the reference's order (interior
  * raster from (1,1) with strides (sw, sh), then the right-edge column x = iw-1-pw, then the bottom-edge row y = ih-1-ph), kept iff
  * the mask window mask[int(y*m) : +int(ph*m), int(x*m) : +int(pw*m)] (clipped like a numpy slice; mask == NULL keeps all) has a

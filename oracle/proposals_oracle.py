@@ -13,10 +13,18 @@ is absent and un-pinned here, so it is restated as a deterministic spec - **pari
       Euclidean distances in float64, ties to the lower cluster index, integer coordinate sums, an empty cluster keeps its
       centre, at most 25 iterations (early exit when no assignment changes).
   mahotas.bwperim: oracle.postprocess_oracle.bwperim.
+  skimage.segmentation.slic (/root/reference/slic.py:43): the published algorithm of skimage's slic_superpixels.py / _slic.pyx (0.15
+      line, the API the reference calls: enforce_connectivity=False, sigma, compactness, min_size_factor unused without
+      connectivity) restated in slic_labels below, with two stated departures that make it deterministic on any hardware: the
+      scaled Lab image is rounded to 2^-20 fixed point (cluster sums become exact integers, independent of the summation order)
+      and a centre that lost all its pixels is dropped (skimage divides by zero there).  The Gaussian pre-filter is
+      scipy.ndimage.gaussian_filter itself (scipy is installed: that stage is pinned by scipy).
 """
 import numpy as np
 
 from .postprocess_oracle import bwperim
+
+SLIC_FIX = float(1 << 20)
 
 HR_NUM_PERIM_SAMPLES = 8          # /root/reference/utils/dataset_hr.py:14-15
 KMEANS_ITERS = 25
@@ -137,3 +145,131 @@ def scannet_candidates(gt_mask, wsi_mask, us_kmeans=4):
                 metadata[patch_id] = {'cnt_xy': scnt, 'perim_xy': perim_points(sub), 'scan_level': 2, 'foreground_indices': sfgi, 'tile_id': patch_id}
                 patch_id += 1
     return metadata
+
+
+# ------------------------------------------------------------------------------------------ SLIC (slic.py:43-75)
+def regular_grid(ar_shape, n_points):
+    """skimage.util.regular_grid: slices that sample ~n_points of an array on a regular grid."""
+    ar_shape = np.asanyarray(ar_shape)
+    ndim = len(ar_shape)
+    unsort_dim_idxs = np.argsort(np.argsort(ar_shape))
+    sorted_dims = np.sort(ar_shape)
+    space_size = float(np.prod(ar_shape))
+    if space_size <= n_points:
+        return [slice(None)] * ndim
+    stepsizes = (space_size / n_points) ** (1.0 / ndim) * np.ones(ndim)
+    if (sorted_dims < stepsizes).any():
+        for dim in range(ndim):
+            stepsizes[dim] = sorted_dims[dim]
+            space_size = float(np.prod(sorted_dims[dim + 1:]))
+            stepsizes[dim + 1:] = ((space_size / n_points) ** (1.0 / (ndim - dim - 1)))
+            if (sorted_dims >= stepsizes).all():
+                break
+    starts = (stepsizes // 2).astype(int)
+    stepsizes = np.round(stepsizes).astype(int)
+    slices = [slice(start, None, step) for start, step in zip(starts, stepsizes)]
+    return [slices[i] for i in unsort_dim_idxs]
+
+
+def rgb2lab(rgb):
+    """skimage.color.rgb2lab (sRGB, illuminant D65, 2 degree observer) of a float image in [0, 1]."""
+    arr = np.asarray(rgb, np.float64).copy()
+    mask = arr > 0.04045
+    arr[mask] = np.power((arr[mask] + 0.055) / 1.055, 2.4)
+    arr[~mask] /= 12.92
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = np.stack([(arr[..., 0] * M[r, 0] + arr[..., 1] * M[r, 1]) + arr[..., 2] * M[r, 2] for r in range(3)], -1)
+    xyz = xyz / np.array([0.95047, 1.0, 1.08883])
+    mask = xyz > 0.008856
+    out = np.where(mask, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    x, y, z = out[..., 0], out[..., 1], out[..., 2]
+    return np.stack([116.0 * y - 16.0, 500.0 * (x - y), 200.0 * (y - z)], -1)
+
+
+def slic_setup(h, w, n_segments):
+    """Initial cluster centres (K, 6) = {cy, cx, 0, 0, 0, alive} on skimage's regular grid of a (1, h, w) volume + the grid steps."""
+    slices = regular_grid((1, h, w), n_segments)
+    step_z, step_y, step_x = [int(s.step if s.step is not None else 1) for s in slices]
+    gy, gx = np.mgrid[:h, :w]
+    sy, sx = gy[slices[1], slices[2]], gx[slices[1], slices[2]]
+    segs = np.zeros((sy.size, 6), np.float64)
+    segs[:, 0], segs[:, 1], segs[:, 5] = sy.ravel(), sx.ravel(), 1.0
+    return segs, step_y, step_x, float(max(step_z, step_y, step_x))
+
+
+def gaussian_weights(sigma, truncate=4.0):
+    """scipy.ndimage._gaussian_kernel1d(sigma, 0, int(truncate * sigma + 0.5))."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def slic_labels(rgb_u8, n_segments=200, compactness=20.0, sigma=5.0, max_iter=10):
+    """labels (H, W) int32 of skimage.segmentation.slic(img_as_float(rgb), n_segments, compactness, sigma=sigma,
+    enforce_connectivity=False) as specified in the module header."""
+    from scipy import ndimage as ndi
+    img = np.asarray(rgb_u8)[..., :3].astype(np.float64) / 255.0                     # img_as_float
+    h, w = img.shape[:2]
+    vol = img[None]
+    if sigma > 0:
+        vol = ndi.gaussian_filter(vol, [sigma, sigma, sigma, 0])
+    lab = rgb2lab(vol[0]) * (1.0 / compactness)
+    q = np.rint(lab * SLIC_FIX).astype(np.int64)                                       # [spec] 2^-20 fixed point
+    col = q.astype(np.float64) / SLIC_FIX
+    segs, step_y, step_x, step = slic_setup(h, w, n_segments)
+    K = len(segs)
+    spatial_weight = 1.0 / (step * step)
+    ys, xs = np.mgrid[:h, :w]
+    labels = np.zeros((h, w), np.int32)
+    for _ in range(max_iter):
+        dist = np.full((h, w), np.finfo(np.float64).max)
+        for k in range(K):                                                             # increasing k + strict '>': ties to the lower centre
+            cy, cx, alive = segs[k, 0], segs[k, 1], segs[k, 5]
+            if not alive:
+                continue
+            y0, y1 = int(max(cy - 2 * step_y, 0.0)), int(min(cy + 2 * step_y + 1, float(h)))
+            x0, x1 = int(max(cx - 2 * step_x, 0.0)), int(min(cx + 2 * step_x + 1, float(w)))
+            if y1 <= y0 or x1 <= x0:
+                continue
+            dy = (cy - ys[y0:y1, x0:x1]) ** 2
+            dx = (cx - xs[y0:y1, x0:x1]) ** 2
+            d = ((0.0 + dy) + dx) * spatial_weight
+            c = col[y0:y1, x0:x1]
+            dc = (c[..., 0] - segs[k, 2]) ** 2
+            dc = dc + (c[..., 1] - segs[k, 3]) ** 2
+            dc = dc + (c[..., 2] - segs[k, 4]) ** 2
+            d = d + dc
+            win = dist[y0:y1, x0:x1]
+            upd = win > d
+            win[upd] = d[upd]
+            labels[y0:y1, x0:x1][upd] = k
+        cnt = np.bincount(labels.ravel(), minlength=K)
+        for k in range(K):
+            if cnt[k] == 0:
+                segs[k, 5] = 0.0                                                       # [spec] an emptied centre is dropped
+                continue
+            sel = labels == k
+            segs[k, 0] = float(ys[sel].sum()) / float(cnt[k])
+            segs[k, 1] = float(xs[sel].sum()) / float(cnt[k])
+            for c in range(3):
+                segs[k, 2 + c] = (float(int(q[..., c][sel].sum())) / SLIC_FIX) / float(cnt[k])
+    return labels
+
+
+def slic_candidates(thumb_rgb_u8, out_hw, n_segments=200, compactness=20.0, sigma=5.0, us_kmeans=4, n_cnt=8):
+    """/root/reference/slic.py:43-75: superpixels of the small thumbnail -> label image at `out_hw` (PIL nearest resize of the
+    uint16 label image) -> per label below labels.max() (the reference's range) key points and perimeter points.  Labels whose
+    key points cannot be computed (get_key_points -> None: too few pixels) are skipped - the reference would store None there
+    and fail in Dataset_eval.  Returns (labels at out_hw, metadata)."""
+    labels = resize_nearest(slic_labels(thumb_rgb_u8, n_segments, compactness, sigma).astype(np.uint16), out_hw)
+    metadata = {}
+    for tile_id in range(int(labels.max())):
+        patch = labels == tile_id
+        n, cnt, _, fgi = get_key_points(patch, us_kmeans, n_cnt)
+        if n is None:
+            continue
+        pc = np.transpose(np.where(bwperim(patch)))[:, ::-1]
+        skip = np.maximum(2, pc.shape[0] // HR_NUM_PERIM_SAMPLES)
+        metadata[tile_id] = {'cnt_xy': cnt, 'perim_xy': pc[::skip, :], 'scan_level': 2, 'foreground_indices': fgi, 'tile_id': tile_id}
+    return labels, metadata

@@ -128,3 +128,29 @@ def test_tile_grid_device_equals_oracle(iw, ih, ph, pw, sh, sw, m, seed):
         want = np.array(WO.tile_grid(iw, ih, ph, pw, sh, sw, mk, m), np.int32).reshape(-1, 2)
         assert got.shape == want.shape and np.array_equal(got, want)
         assert np.array_equal(got, S.tile_grid(iw, ih, ph, pw, sh, sw, mk, m))
+
+
+# ------------------------------------------------------------------------------ SLIC (slic.py:43-75)
+@pytest.mark.parametrize('seed,hw,nseg,sigma', [(0, (180, 240), 200, 5.0), (1, (97, 131), 60, 3.0), (2, (128, 128), 100, 0.0),
+                                               (3, (300, 210), 200, 5.0)])
+def test_slic_labels_exact(P, seed, hw, nseg, sigma):
+    """wsi_slic == oracle slic_labels on seeded thumbnails: identical labels (the Gaussian pass is scipy's summation order, the
+    cluster sums are exact integers, ties go to the lower centre on both sides)."""
+    from tests.test_proposals_oracle import _thumb
+    img = _thumb(seed, hw)
+    got = P.slic(torch.from_numpy(img).cuda(), nseg, 20.0, sigma).cpu().numpy()
+    ref = PO.slic_labels(img, nseg, 20.0, sigma)
+    nd = int((got != ref).sum())
+    print('slic %s: %d superpixels, %d / %d pixels differ' % (hw, len(np.unique(ref)), nd, ref.size))
+    assert nd == 0
+
+
+def test_slic_candidates_metadata_exact(P):
+    from tests.test_proposals_oracle import _thumb
+    img = _thumb(7, (120, 160))
+    labels, meta = P.slic_candidates(torch.from_numpy(img).cuda(), (480, 640), 80, 20.0, 5.0)
+    rl, rm = PO.slic_candidates(img, (480, 640), 80, 20.0, 5.0)
+    assert np.array_equal(labels.cpu().numpy(), rl) and sorted(meta) == sorted(rm) and len(meta) > 20
+    for k in meta:
+        assert np.array_equal(meta[k]['cnt_xy'], rm[k]['cnt_xy']) and np.array_equal(meta[k]['perim_xy'], rm[k]['perim_xy'])
+        assert all(np.array_equal(a, b) for a, b in zip(meta[k]['foreground_indices'], rm[k]['foreground_indices']))

@@ -67,3 +67,67 @@ def test_key_points_and_candidates():
     for k, r in meta.items():
         assert r['tile_id'] == k and r['cnt_xy'].shape[1] == 2 and r['perim_xy'].shape[1] == 2
         assert len(r['foreground_indices'][0]) > 0
+
+
+# ------------------------------------------------------------------------------ SLIC specification (slic.py:43)
+def _thumb(seed, hw):
+    """Smooth colour fields + blobs: an H&E-like thumbnail on which superpixels have something to follow."""
+    rng = np.random.default_rng(seed)
+    h, w = hw
+    yy, xx = np.mgrid[:h, :w]
+    img = np.empty((h, w, 3), np.float64)
+    for c in range(3):
+        img[..., c] = 200 + 30 * np.sin(yy / (7.0 + c) + rng.uniform(0, 6)) * np.cos(xx / (9.0 + 2 * c) + rng.uniform(0, 6))
+    for _ in range(6):
+        cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(6, 20)
+        sel = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        img[sel] = rng.uniform(60, 200, 3)
+    img += rng.normal(0, 4, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_slic_building_blocks():
+    from scipy import ndimage as ndi
+    # rgb2lab on known colours (published values: white L = 100, sRGB red = (53.24, 80.09, 67.20))
+    lab = PO.rgb2lab(np.array([[[1.0, 1.0, 1.0], [0.0, 0.0, 0.0], [1.0, 0.0, 0.0]]]))
+    assert np.allclose(lab[0, 0], (100.0, 0.0, 0.0), atol=2e-2) and np.allclose(lab[0, 1], 0.0, atol=1e-9)
+    assert np.allclose(lab[0, 2], (53.24, 80.09, 67.20), atol=5e-2)
+    # the Gaussian weights are scipy's, and the separable symmetric pass reproduces scipy bit for bit
+    fw, radius = PO.gaussian_weights(5.0)
+    assert radius == 20 and len(fw) == 41 and abs(fw.sum() - 1) < 1e-15
+    x = np.random.default_rng(1).random((1, 23, 31, 3))
+    ref = ndi.gaussian_filter(x, [5.0, 5.0, 5.0, 0])
+
+    def sym_pass(a, axis):
+        n = a.shape[axis]
+        idx = np.arange(-radius, n + radius)
+        idx = np.mod(idx, 2 * n)
+        idx = np.where(idx < n, idx, 2 * n - 1 - idx)                      # scipy 'reflect'
+        ext = np.take(a, idx, axis)
+        sl = lambda o: np.take(ext, np.arange(n) + radius + o, axis)
+        out = sl(0) * fw[radius]
+        for jj in range(-radius, 0):
+            out = out + (sl(jj) + sl(-jj)) * fw[radius + jj]
+        return out
+    got = sym_pass(sym_pass(sym_pass(x, 0), 1), 2)
+    assert np.array_equal(got, ref)                                        # the order of summation the device kernel uses
+    # the regular grid: ~n_segments centres, steps as skimage computes them
+    segs, sy, sx, step = PO.slic_setup(150, 200, 200)
+    assert 150 <= len(segs) <= 260 and step == max(sy, sx) and segs[:, 5].all() and not segs[:, 2:5].any()
+
+
+@pytest.mark.parametrize('seed,hw,nseg,sigma', [(0, (90, 120), 60, 3.0), (1, (64, 64), 30, 0.0)])
+def test_slic_labels_properties(seed, hw, nseg, sigma):
+    img = _thumb(seed, hw)
+    lab = PO.slic_labels(img, nseg, 20.0, sigma)
+    assert np.array_equal(lab, PO.slic_labels(img.copy(), nseg, 20.0, sigma))      # deterministic
+    segs, sy, sx, _ = PO.slic_setup(hw[0], hw[1], nseg)
+    assert lab.min() >= 0 and lab.max() < len(segs) and len(np.unique(lab)) >= 0.7 * len(segs)
+    # every pixel lies inside the final window of some centre: no superpixel is wider than 4 steps + 1
+    for k in np.unique(lab):
+        ys, xs = np.nonzero(lab == k)
+        assert ys.max() - ys.min() <= 4 * sy + 1 and xs.max() - xs.min() <= 4 * sx + 1
+    labels, meta = PO.slic_candidates(img, (hw[0] * 2, hw[1] * 2), nseg, 20.0, sigma, us_kmeans=2, n_cnt=3)
+    assert labels.shape == (hw[0] * 2, hw[1] * 2) and len(meta) >= 0.5 * len(np.unique(lab))
+    for k, r in meta.items():
+        assert r['cnt_xy'].shape == (3, 2) and r['perim_xy'].shape[1] == 2 and (labels[r['foreground_indices']] == k).all()

@@ -84,6 +84,9 @@ static inline uint16_t f16_bits(float x) {
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 long long wsi_tile_grid_candidates_impl(int iw, int ih, int ph, int pw, int sh, int sw);
+size_t wsi_slic_scratch_bytes_impl(int H, int W, int K);
+int wsi_slic_dispatch(const uint8_t* rgb, int H, int W, const double* fw, int radius, double* segs, int K, int step_y, int step_x,
+                      double step, double compactness, int iters, int* labels, void* scratch, hipStream_t st);
 size_t wsi_tile_grid_scratch_bytes_impl(long long n);
 int wsi_tile_grid_dispatch(int iw, int ih, int ph, int pw, int sh, int sw, const uint8_t* mask, int MH, int MW, double m, double thresh,
                            int* out_xy, int* count_out, void* scratch, hipStream_t st);
@@ -554,6 +557,12 @@ size_t wsi_connected_components_scratch_bytes(int h, int w) { return (h <= 0 || 
 int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream) {
     if (!mask || !labels_out || !scratch) return WSI_EINVAL;
     return wsi_cc_dispatch(mask, h, w, labels_out, count_out, scratch, (hipStream_t)stream);
+}
+size_t wsi_slic_scratch_bytes(int h, int w, int k) { return wsi_slic_scratch_bytes_impl(h, w, k); }
+int wsi_slic(const uint8_t* rgb, int h, int w, const double* gauss_weights, int radius, double* segments, int k, int step_y, int step_x,
+             double step, double compactness, int iters, int* labels_out, void* scratch, void* stream) {
+    return wsi_slic_dispatch(rgb, h, w, gauss_weights, radius, segments, k, step_y, step_x, step, compactness, iters, labels_out, scratch,
+                             (hipStream_t)stream);
 }
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream) {
     if (!points_xy || !centres_xy || !labels_out || !scratch) return WSI_EINVAL;

@@ -131,6 +131,162 @@ __global__ void kmeans_update_kernel(double* centres, int k, const unsigned long
     }
 }
 
+// ------------------------------------------------------------------------------------------ SLIC superpixels
+// skimage.segmentation.slic as /root/reference/slic.py:43 calls it (n_segments = 200, compactness = 20, sigma = 5,
+// enforce_connectivity = False) on a 2-D RGB thumbnail; skimage is absent, so this follows its published algorithm
+// (slic_superpixels.py / _slic.pyx of the 0.15 line) as an own deterministic specification, oracle/proposals_oracle.py slic_labels:
+//   img_as_float -> scipy.ndimage.gaussian_filter (reflect, truncate 4; the size-1 depth axis is filtered too) -> rgb2lab ->
+//   * (1 / compactness) -> [spec] rounded to 2^-20 fixed point, so that the cluster sums are exact integers and do not depend on
+//   the summation order -> 10 rounds of {assign: every centre claims the pixels of its (4 step + 1)^2 window it is nearest to,
+//   ties to the lower centre; update: centre = mean position, mean colour}.  Centres start on skimage's regular grid with
+//   colour 0.  [spec] a centre that lost all its pixels is dropped (skimage divides by zero there).
+// Thumbnail-sized float64 work; one thread per pixel, centres in LDS.
+#define SLIC_FIX 1048576.0                                            // 2^20
+#define SLIC_MAXK 2048
+static __device__ __forceinline__ int slic_reflect(int p, int n) {   // scipy 'reflect': d c b a | a b c d | d c b a
+    const int m = 2 * n;
+    p %= m;
+    if (p < 0) p += m;
+    return p < n ? p : m - 1 - p;
+}
+// one separable pass of correlate1d with a symmetric kernel, in scipy's summation order: centre first, then the pairs from
+// the outermost inwards.  axis 0 = the size-1 depth axis (every neighbour reflects onto the pixel itself), 1 = rows, 2 = columns.
+__global__ __launch_bounds__(256) void slic_blur_kernel(const double* in, const uint8_t* rgb, double* out, int H, int W, const double* fw,
+                                                        int radius, int axis) {
+    const long long n = (long long)H * W * 3;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % 3);
+        const long long px = i / 3;
+        const int x = (int)(px % W), y = (int)(px / W);
+        auto at = [&](int yy, int xx) -> double {
+            const long long j = ((long long)yy * W + xx) * 3 + c;
+            return rgb ? (double)rgb[j] / 255.0 : in[j];              // img_as_float of a uint8 image
+        };
+        double tmp = at(y, x) * (radius ? fw[radius] : 1.0);          // radius 0 (sigma = 0): skimage skips the filter
+        for (int jj = -radius; jj < 0; ++jj) {
+            double a, b;
+            if (axis == 0) { a = at(y, x); b = a; }
+            else if (axis == 1) { a = at(slic_reflect(y + jj, H), x); b = at(slic_reflect(y - jj, H), x); }
+            else { a = at(y, slic_reflect(x + jj, W)); b = at(y, slic_reflect(x - jj, W)); }
+            tmp += (a + b) * fw[radius + jj];
+        }
+        out[i] = tmp;
+    }
+}
+// skimage rgb2lab (sRGB, D65, 2 degree observer) * ratio, rounded to 2^-20 fixed point
+__global__ __launch_bounds__(256) void slic_lab_kernel(const double* rgb, long long npix, double ratio, int* q) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        double v[3], xyz[3];
+        for (int c = 0; c < 3; ++c) {
+            const double a = rgb[i * 3 + c];
+            v[c] = a > 0.04045 ? pow((a + 0.055) / 1.055, 2.4) : a / 12.92;
+        }
+        const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+        const double white[3] = {0.95047, 1.0, 1.08883};
+        for (int r = 0; r < 3; ++r) {
+            double t = v[0] * M[r][0];                                 // arr @ M.T: a sequential dot product
+            t += v[1] * M[r][1];
+            t += v[2] * M[r][2];
+            t = t / white[r];
+            xyz[r] = t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0;
+        }
+        const double lab[3] = {116.0 * xyz[1] - 16.0, 500.0 * (xyz[0] - xyz[1]), 200.0 * (xyz[1] - xyz[2])};
+        for (int c = 0; c < 3; ++c) q[i * 3 + c] = (int)llrint(lab[c] * ratio * SLIC_FIX);
+    }
+}
+// segs[k] = {cy, cx, c0, c1, c2, alive}
+__global__ __launch_bounds__(256) void slic_assign_kernel(const int* q, int H, int W, const double* segs, int K, int step_y, int step_x,
+                                                          double spatial_weight, int* labels) {
+    __shared__ double sg[1024 * 6];
+    const long long n = (long long)H * W;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    const int x = i < n ? (int)(i % W) : 0, y = i < n ? (int)(i / W) : 0;
+    double col[3] = {0, 0, 0};
+    if (i < n)
+        for (int c = 0; c < 3; ++c) col[c] = (double)q[i * 3 + c] / SLIC_FIX;
+    double best = 1.7976931348623157e308;
+    int bk = i < n ? labels[i] : 0;
+    for (int k0 = 0; k0 < K; k0 += 1024) {                            // 1024 centres (48 KB) per LDS round
+        const int kn = min(1024, K - k0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < kn * 6; j += 256) sg[j] = segs[(size_t)k0 * 6 + j];
+        __syncthreads();
+        if (i >= n) continue;
+        for (int k = 0; k < kn; ++k) {
+            const double* s = sg + k * 6;
+            if (s[5] == 0.0) continue;
+            const double cy = s[0], cx = s[1];
+            const long long y_min = (long long)fmax(cy - 2 * step_y, 0.0), y_max = (long long)fmin(cy + 2 * step_y + 1, (double)H);
+            const long long x_min = (long long)fmax(cx - 2 * step_x, 0.0), x_max = (long long)fmin(cx + 2 * step_x + 1, (double)W);
+            if (y < y_min || y >= y_max || x < x_min || x >= x_max) continue;
+            const double dy = (cy - y) * (cy - y);                      // dz = 0: depth 1, centre z = 0
+            const double dx = (cx - x) * (cx - x);
+            double d = (0.0 + dy + dx) * spatial_weight;
+            double dc = 0.0;
+            for (int c = 0; c < 3; ++c) dc += (col[c] - s[2 + c]) * (col[c] - s[2 + c]);
+            d += dc;
+            if (best > d) { best = d; bk = k0 + k; }
+        }
+    }
+    if (i < n) labels[i] = bk;
+}
+__global__ __launch_bounds__(256) void slic_sum_kernel(const int* q, int H, int W, const int* labels, unsigned long long* sums) {
+    const long long n = (long long)H * W;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        unsigned long long* s = sums + (size_t)labels[i] * 6;
+        atomicAdd(&s[0], 1ull);
+        atomicAdd(&s[1], (unsigned long long)(i / W));
+        atomicAdd(&s[2], (unsigned long long)(i % W));
+        for (int c = 0; c < 3; ++c) atomicAdd(&s[3 + c], (unsigned long long)(long long)q[i * 3 + c]);   // two's complement: exact signed sums
+    }
+}
+__global__ void slic_update_kernel(const unsigned long long* sums, double* segs, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long long cnt = (long long)sums[k * 6];
+    double* s = segs + (size_t)k * 6;
+    if (cnt == 0) { s[5] = 0.0; return; }
+    s[0] = (double)(long long)sums[k * 6 + 1] / (double)cnt;
+    s[1] = (double)(long long)sums[k * 6 + 2] / (double)cnt;
+    for (int c = 0; c < 3; ++c) s[2 + c] = ((double)(long long)sums[k * 6 + 3 + c] / SLIC_FIX) / (double)cnt;
+}
+
+size_t wsi_slic_scratch_bytes_impl(int H, int W, int K) {
+    if (H <= 0 || W <= 0 || K <= 0 || K > SLIC_MAXK) return 0;
+    const size_t npix = (size_t)H * W;
+    return 2 * npix * 3 * sizeof(double) + npix * 3 * sizeof(int) + (size_t)K * 6 * sizeof(unsigned long long) + 256;
+}
+// rgb (H, W, 3) u8; fw: the 2 radius + 1 Gaussian weights (device, float64; radius 0 = no filter); segs (K, 6) float64 in / out;
+// labels (H, W) int32 out
+int wsi_slic_dispatch(const uint8_t* rgb, int H, int W, const double* fw, int radius, double* segs, int K, int step_y, int step_x,
+                      double step, double compactness, int iters, int* labels, void* scratch, hipStream_t st) {
+    if (!rgb || !segs || !labels || !scratch || wsi_slic_scratch_bytes_impl(H, W, K) == 0 || iters < 1 || radius < 0 || (radius && !fw) ||
+        step_y < 1 || step_x < 1 || !(step > 0) || !(compactness > 0)) return WSI_EINVAL;
+    const long long npix = (long long)H * W;
+    double* a = (double*)scratch;
+    double* b = a + npix * 3;
+    int* q = (int*)(b + npix * 3);
+    unsigned long long* sums = (unsigned long long*)(((uintptr_t)(q + npix * 3) + 255) & ~(uintptr_t)255);
+    const int g3 = (int)((npix * 3 + 255) / 256 > 65535 * 16 ? 65535 * 16 : (npix * 3 + 255) / 256), g1 = (int)((npix + 255) / 256);
+    if (radius) {
+        hipLaunchKernelGGL(slic_blur_kernel, dim3(g3), dim3(256), 0, st, (const double*)nullptr, rgb, a, H, W, fw, radius, 0);
+        hipLaunchKernelGGL(slic_blur_kernel, dim3(g3), dim3(256), 0, st, (const double*)a, (const uint8_t*)nullptr, b, H, W, fw, radius, 1);
+        hipLaunchKernelGGL(slic_blur_kernel, dim3(g3), dim3(256), 0, st, (const double*)b, (const uint8_t*)nullptr, a, H, W, fw, radius, 2);
+    } else {                                                           // no filter: a = img_as_float(rgb)
+        hipLaunchKernelGGL(slic_blur_kernel, dim3(g3), dim3(256), 0, st, (const double*)nullptr, rgb, a, H, W, fw, 0, 1);
+    }
+    hipLaunchKernelGGL(slic_lab_kernel, dim3(g1 > 65535 * 16 ? 65535 * 16 : g1), dim3(256), 0, st, (const double*)a, npix, 1.0 / compactness, q);
+    if (hipMemsetAsync(labels, 0, (size_t)npix * sizeof(int), st) != hipSuccess) return WSI_EFAULT;
+    const double spatial_weight = 1.0 / (step * step);
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(slic_assign_kernel, dim3(g1), dim3(256), 0, st, (const int*)q, H, W, (const double*)segs, K, step_y, step_x, spatial_weight, labels);
+        if (hipMemsetAsync(sums, 0, (size_t)K * 6 * sizeof(unsigned long long), st) != hipSuccess) return WSI_EFAULT;
+        hipLaunchKernelGGL(slic_sum_kernel, dim3(g1 > 4096 ? 4096 : g1), dim3(256), 0, st, (const int*)q, H, W, (const int*)labels, sums);
+        hipLaunchKernelGGL(slic_update_kernel, dim3((K + 255) / 256), dim3(256), 0, st, (const unsigned long long*)sums, segs, K);
+    }
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
 // ------------------------------------------------------------------------------------------ tile grid (sliding-window path)
 // /root/reference/utils/dataset.py:143-166: candidates in the reference's order (interior raster, right-edge column, bottom-edge
 // row, no corner), kept iff the level-2 mask window mask[yp:yp+dy, xp:xp+dx] (numpy slice clipping) is >= thresh nonzero.

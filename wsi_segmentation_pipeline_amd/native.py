@@ -36,7 +36,7 @@ class WsiUnetDecoderWeights(C.Structure):
     ]
 
 
-_vp, _i, _ll, _sz, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_float
+_vp, _i, _ll, _sz, _f, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_float, C.c_double
 # name -> (restype, argtypes); must list every symbol include/wsi_hip.h declares
 SIGNATURES = {
     'wsi_hip_abi_version': (_i, []),
@@ -90,6 +90,8 @@ SIGNATURES = {
     'wsi_connected_components_scratch_bytes': (_sz, [_i, _i]),
     'wsi_connected_components': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     'wsi_kmeans_points': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'wsi_slic_scratch_bytes': (_sz, [_i, _i, _i]),
+    'wsi_slic': (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
     'wsi_tile_grid_candidates': (_ll, [_i, _i, _i, _i, _i, _i]),
     'wsi_tile_grid_scratch_bytes': (_sz, [_ll]),
     'wsi_tile_grid': (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),

@@ -128,3 +128,76 @@ def scannet_candidates(gt_mask, wsi_mask, us_kmeans=4):
                 metadata[patch_id] = {'cnt_xy': scnt, 'perim_xy': _perim_points(sub), 'scan_level': 2, 'foreground_indices': sfgi, 'tile_id': patch_id}
                 patch_id += 1
     return metadata
+
+
+# ------------------------------------------------------------------------------------------ SLIC candidates (reference slic.py:43-75)
+def _regular_grid(ar_shape, n_points):
+    """skimage.util.regular_grid (host arithmetic on three numbers)."""
+    ar_shape = np.asanyarray(ar_shape)
+    ndim = len(ar_shape)
+    unsort = np.argsort(np.argsort(ar_shape))
+    sorted_dims = np.sort(ar_shape)
+    space = float(np.prod(ar_shape))
+    if space <= n_points:
+        return [slice(None)] * ndim
+    steps = (space / n_points) ** (1.0 / ndim) * np.ones(ndim)
+    if (sorted_dims < steps).any():
+        for dim in range(ndim):
+            steps[dim] = sorted_dims[dim]
+            space = float(np.prod(sorted_dims[dim + 1:]))
+            steps[dim + 1:] = ((space / n_points) ** (1.0 / (ndim - dim - 1)))
+            if (sorted_dims >= steps).all():
+                break
+    starts = (steps // 2).astype(int)
+    steps = np.round(steps).astype(int)
+    slices = [slice(a, None, b) for a, b in zip(starts, steps)]
+    return [slices[i] for i in unsort]
+
+
+def slic(rgb_u8, n_segments=200, compactness=20.0, sigma=5.0, max_iter=10):
+    """skimage.segmentation.slic(img_as_float(rgb), n_segments, compactness, sigma=sigma, enforce_connectivity=False) of an (H,W,3)
+    uint8 GPU image on the device (wsi_slic; specification: oracle/proposals_oracle.py slic_labels - own deterministic spec of the
+    published algorithm, parity unpinned).  Returns int32 labels (H,W)."""
+    lib = native.load()
+    _require_gpu(rgb_u8, 'thumbnail')
+    if rgb_u8.dtype != torch.uint8 or rgb_u8.dim() != 3 or rgb_u8.shape[2] < 3:
+        raise ValueError('expected an (H,W,3) uint8 image')
+    img = rgb_u8[..., :3].contiguous()
+    h, w = int(img.shape[0]), int(img.shape[1])
+    sl = _regular_grid((1, h, w), n_segments)
+    step_z, step_y, step_x = [int(s.step if s.step is not None else 1) for s in sl]
+    gy, gx = np.mgrid[:h, :w]
+    sy, sx = gy[sl[1], sl[2]], gx[sl[1], sl[2]]
+    segs = np.zeros((sy.size, 6), np.float64)
+    segs[:, 0], segs[:, 1], segs[:, 5] = sy.ravel(), sx.ravel(), 1.0
+    k = len(segs)
+    radius, fw = 0, None
+    if sigma > 0:                                                # scipy.ndimage._gaussian_kernel1d, truncate = 4
+        radius = int(4.0 * float(sigma) + 0.5)
+        xk = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * xk ** 2)
+        fw = torch.from_numpy(phi / phi.sum()).to(img.device)
+    segs_d = torch.from_numpy(segs).to(img.device)
+    labels = torch.empty((h, w), dtype=torch.int32, device=img.device)
+    nbytes = lib.wsi_slic_scratch_bytes(h, w, k)
+    if nbytes == 0:
+        raise ValueError('slic: %d segments on a %dx%d image is outside the kernel\'s range' % (k, h, w))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+    native.check(lib.wsi_slic(_ptr(img), h, w, _ptr(fw) if fw is not None else None, radius, _ptr(segs_d), k, step_y, step_x,
+                              float(max(step_z, step_y, step_x)), float(compactness), int(max_iter), _ptr(labels), _ptr(scratch), _stream()),
+                 'wsi_slic')
+    return labels
+
+
+def slic_candidates(thumb_rgb_u8, out_hw, n_segments=200, compactness=20.0, sigma=5.0, us_kmeans=4, n_cnt=8):
+    """reference slic.py:43-75 on the device: superpixel labels of the small thumbnail, nearest-resized to `out_hw`, then per label
+    below labels.max() the key points (get_key_points) and perimeter points.  Returns (labels (H,W) int32 GPU tensor, metadata)."""
+    labels = _resize_nearest(slic(thumb_rgb_u8, n_segments, compactness, sigma), out_hw)
+    metadata = {}
+    for tile_id in range(int(labels.max().item())):
+        patch = labels == tile_id
+        n, cnt, _, fgi = get_key_points(patch, us_kmeans, n_cnt)
+        if n is None:
+            continue
+        metadata[tile_id] = {'cnt_xy': cnt, 'perim_xy': _perim_points(patch), 'scan_level': 2, 'foreground_indices': fgi, 'tile_id': tile_id}
+    return labels, metadata
