@@ -17,5 +17,15 @@ for key in sorted(acc):
     print(key[0], 'grid', key[1], 'wg', key[2], 'n=%d' % len(next(iter(acc[key].values()))))
     for k in sorted(vals):
         print('    %-32s %.4g' % (k, vals[k]))
-    if 'SQ_VALU_MFMA_BUSY_CYCLES' in vals and 'SQ_BUSY_CYCLES' in vals:
-        pass
+    g = vals.get
+    if g('SQ_VALU_MFMA_BUSY_CYCLES') and g('SQ_BUSY_CYCLES'):
+        # SQ_BUSY_CYCLES counts per SE-quad; the *_BUSY / ACTIVE ratios below are per-SIMD shares of the kernel's busy time
+        derived = {}
+        if g('SQ_INSTS_VALU') and g('SQ_INSTS_MFMA'):
+            derived['VALU instructions per MFMA (SQ_INSTS_VALU includes the MFMAs)'] = (g('SQ_INSTS_VALU') - g('SQ_INSTS_MFMA')) / g('SQ_INSTS_MFMA')
+        if g('SQ_LDS_IDX_ACTIVE') and g('SQ_LDS_BANK_CONFLICT') is not None:
+            derived['LDS bank-conflict cycles / LDS active cycles'] = g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE')
+        if g('SQ_WAVE_CYCLES') and g('SQ_WAIT_ANY') is not None:
+            derived['share of wave lifetime waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES)'] = g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES')
+        for k, v in derived.items():
+            print('    -> %-60s %.3f' % (k, v))

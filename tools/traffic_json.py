@@ -25,7 +25,7 @@ for name, d in acc.items():
                  'hbm_bytes_per_launch': fetch + write}
 slab = {k: v for k, v in res.items() if 'conv3x3s1_' in k}      # slab3 + wide: all stride-1 3x3 launches
 tot_l = sum(v['launches'] for v in slab.values())
-summary = {'bench_args': sys.argv[3:], 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 (gfx950), KiB units',
+summary = {'bench_args': sys.argv[3:], 'batch': 1000, 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 (gfx950), KiB units',
            'kernels': res,
            'conv3x3_s1_hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in slab.values()) / max(tot_l, 1)}
 json.dump(summary, open(dst, 'w'), indent=1)

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            const int i = i0 + wm * MT * 32 + mt * 32 + (a.gi.W < 32 ? dense_lane_pixel(l31) : l31);   // (conv_dev.h: LDS bank conflicts)
             valid[mt] = i < R;
             qs[mt] = pos(valid[mt] ? i : i1);
             xoff[mt] = qs[mt] - slab0 - (P + 1);             // tap (0,0) adds toff relative to q - P - 1
@@ -345,6 +345,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     int xoff[MT], qs[MT];
     bool valid[MT];
     int slab0, npieces;
+    const int lpix = a.gi.W < 32 ? dense_lane_pixel(l31) : l31;      // bank-conflict-free lane order on narrow maps (conv_dev.h)
     {
         const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
         auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            const int i = i0 + wm * MT * 32 + mt * 32 + lpix;
             valid[mt] = i < R;
             qs[mt] = pos(valid[mt] ? i : i1);
             xoff[mt] = qs[mt] - slab0 - (P + 1);
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         qlast = pos(i1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int i = i0 + wm * MT * 32 + mt * 32 + l31;
+            const int i = i0 + wm * MT * 32 + mt * 32 + (a.go.W < 32 ? dense_lane_pixel(l31) : l31);   // (conv_dev.h: LDS bank conflicts)
             valid[mt] = i < R;
             qs[mt] = pos(valid[mt] ? i : i1);
         }

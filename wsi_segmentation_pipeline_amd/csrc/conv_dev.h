@@ -355,6 +355,17 @@ static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8
     }
 }
 
+// Lane -> pixel of a 32-pixel MFMA tile for DENSE tiles.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} and
+// {4-11, 16-19, 28-31} (+32 for the upper half) and is conflict-free when a group's 16 pixels are distinct modulo 16 in the
+// slab.  With lane = pixel, the pad column a dense tile skips puts two of a group's pixels on one bank on maps narrower than
+// 32 (r03 counters of the wide kernel: 39 % of its LDS cycles on 16x16 and 8x8 maps were conflict cycles, none on 32x32); giving
+// each group 16 CONSECUTIVE pixels (one row of a 16-wide map, two of an 8-wide one) removes it at 16 and leaves one 2-way
+// conflict per read at 8.  Any lane order is legal: a lane is just a column of the MFMA tile, and the epilogue stores by the
+// same map.
+static __device__ __forceinline__ int dense_lane_pixel(int l31) {
+    return l31 < 4 ? l31 : l31 < 12 ? l31 + 12 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 12 : l31;
+}
+
 // LDS byte offset of slot-pair base for slab-local pixel Pl and lane half h (swizzled):
 // slot s = 2f + h is stored at slot s ^ ((Pl>>1)&7); fragment f is reached by XOR (f<<5).
 static __device__ __forceinline__ int lds_xbase(int Pl, int h) { return Pl * 128 + ((h ^ ((Pl >> 1) & 7)) << 4); }

@@ -61,13 +61,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
     int xoff[MT], qs[MT];
     bool valid[MT];
     int slab0, npieces;
-    // Lane -> pixel of a 32-pixel MFMA tile.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19,
-    // 28-31} (+32 for the upper half) and is conflict-free when a group's 16 pixels are distinct modulo 16 in the slab.  With
-    // lane = pixel, the pad column skipped inside a dense tile of a 16-wide map puts two of them on one bank (one extra LDS
-    // cycle per group: the 44 % conflict rate of the r01 counters); giving each group 16 CONSECUTIVE pixels (= one whole row
-    // of a 16-wide map, two for 32) removes it.  Any lane order is legal: a lane is just a column of the MFMA tile, and the
-    // epilogue stores by the same map.
-    const int lpix = l31 < 4 ? l31 : l31 < 12 ? l31 + 12 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 12 : l31;
+    const int lpix = dense_lane_pixel(l31);                   // lane -> pixel of a 32-pixel tile: conv_dev.h (LDS bank conflicts)
     {
         const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
         auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
