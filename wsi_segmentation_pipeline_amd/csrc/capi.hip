@@ -346,6 +346,7 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
 
 static int g_s2_slab = 1;                             // stride-2 convs: phase-slab kernel (1) or per-tap gather kernel (0)
 static int g_s2_split = 1;                            // trunk: phase-split stage outputs + wide stride-2 kernel (A/B: wsi_conv_set_mode +128 off)
+static int g_ds_fold = 1;                             // trunk, mode 3: the strided blocks' 1x1 downsample runs inside their second conv (A/B: +2048 off)
 
 #ifdef WSI_STUDY
 static void* g_study_debug = nullptr;                 // study builds: device buffer handed to stamped kernels through ConvArgs.out2
@@ -354,7 +355,8 @@ extern "C" int wsi_study_set_debug(void* dev_buf) { g_study_debug = dev_buf; ret
 
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
-                       int cfg = -1, int split_out = 0, long long split_pixels = 0) {
+                       int cfg = -1, int split_out = 0, long long split_pixels = 0, const void* in2 = nullptr, int in2_c = 0,
+                       const void* wpk2 = nullptr, const float* bias2 = nullptr) {
     if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
     if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
     ConvArgs a;
@@ -377,6 +379,11 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     if (relu & ~1) return WSI_EINVAL;
 #endif
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
+    if (in2) {                                         // extra K segment (common.h ConvArgs.in2): mode 3, stride-1 3x3, wide kernel only
+        if (planes != 3 || stride != 1 || ksize != 3 || resid_pf || !wpk2 || !bias2 || in2_c <= 0 || in2_c % 32 || cout % 128 || cfg >= 0) return WSI_EINVAL;
+        a.in2 = in2; a.in2_c = in2_c; a.wpk2 = wpk2; a.bias2 = bias2;
+        cfg = 60;
+    }
 #ifdef WSI_STUDY
     if (cfg == 75 || cfg == 76) a.out2 = g_study_debug;
 #endif
@@ -420,7 +427,8 @@ int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* 
 static int s2_split_common(const void* in_split, void* out_conv_pf, void* out_ds_pf, const void* wpk3,
                            const float* bias3, const void* wpk1, const float* bias1, int n, int h_in, int w_in,
                            int cin, int cout, int planes, void* stream, long long split_pixels) {
-    if (!in_split || !out_conv_pf || !out_ds_pf || !wpk3 || !bias3 || !wpk1 || !bias1 || n <= 0 || h_in % 2 || w_in % 2)
+    // out_ds_pf == null: the 3x3 conv alone (the trunk then computes the downsample inside the block's second conv)
+    if (!in_split || !out_conv_pf || !wpk3 || !bias3 || (out_ds_pf && (!wpk1 || !bias1)) || n <= 0 || h_in % 2 || w_in % 2)
         return WSI_EINVAL;
     if (in_split == out_conv_pf || in_split == out_ds_pf || out_conv_pf == out_ds_pf) return WSI_EINVAL;
     ConvArgs a;
@@ -428,7 +436,7 @@ static int s2_split_common(const void* in_split, void* out_conv_pf, void* out_ds
     a.gi = pf_geom_fd(n, h_in, w_in, cin);
     a.go = pf_geom_fd(n, h_in / 2, w_in / 2, cout);
     a.stride = 2; a.ksize = 3; a.relu = 1; a.flags = 0;
-    a.out2 = out_ds_pf; a.wpk2 = wpk1; a.bias2 = bias1;
+    a.out2 = out_ds_pf; a.wpk2 = out_ds_pf ? wpk1 : nullptr; a.bias2 = out_ds_pf ? bias1 : nullptr;
     a.out_split_pixels = 0;
     a.in_split_pixels = split_pixels ? split_pixels : pf_alloc_pixels(n, h_in / 2, w_in / 2);
     return wsi_s2_dispatch(a, planes, (hipStream_t)stream);      // EINVAL outside the wide kernel's range (output maps wider than 33)
@@ -464,6 +472,7 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
 extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_ranges;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
+    g_ds_fold = (s2_slab & 2048) ? 0 : 1;
     g_xcd_ranges = (s2_slab & 256) ? 0 : (s2_slab & 512) ? 1 : 2;          // +256: off, +512: 64-channel layer only
     g_s2_ablate = (s2_slab & 64) ? 1 : 0;                 // bottleneck study only: stride-2 kernel without weight loads (wrong results)
     g_xcd_order = (s2_slab & 8) ? 1 : 0;
@@ -824,12 +833,17 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             const int wi = s * 4 + b * 2;
             void *mid, *out;
             const void* resid;
+            // r03, mode 3: the 1x1 downsample of a strided block is computed INSIDE the block's second conv as an extra K segment
+            // over phase 00 of the block input (ConvArgs.in2): the stride-2 kernel drops its second accumulator set and half its
+            // tile epilogues, the downsample tensor is neither written nor read back as a residual
+            const bool fold = b == 0 && x_split && planes == 3 && g_ds_fold && g_s2_slab && C % 128 == 0;
+            const void* fold_in2 = fold ? x : nullptr;
             if (b == 0) {                              // strided block with 1x1 downsample branch
                 mid = ws + p.buf[s][1];
-                void* ds = ws + p.buf[s][2];
+                void* ds = fold ? nullptr : ws + p.buf[s][2];
                 out = ws + p.buf[s][0];
                 if (g_s2_slab) {
-                    const int pi_ = prof_open(st, 2, 2.0 * n * H * W * (double)C * (C / 2) * 10);
+                    const int pi_ = prof_open(st, 2, 2.0 * n * H * W * (double)C * (C / 2) * (fold ? 9 : 10));
                     rc = x_split ? s2_split_common(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1],
                                                    wt->down_b[s - 1], n, 2 * H, 2 * W, C / 2, C, planes, st, pf_alloc_pixels(cap, H, W))
                                  : wsi_conv3x3s2_ds_fused(x, mid, ds, wt->conv_w[wi], wt->conv_b[wi], wt->down_w[s - 1], wt->down_b[s - 1], n,
@@ -855,7 +869,14 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                 cur = o;
                 last_off = p.buf[s][o];
             }
-            if (b == 1 && can_split(s)) {              // the stage's output feeds only the next stage's stride-2 entry
+            if (fold_in2) {                            // second conv of a strided block with the downsample folded in (never the stage's last conv)
+                const int pi_ = prof_open(st, 1, 2.0 * n * H * W * (double)C * (C * 9 + C / 2));
+                rc = conv_common(mid, out, nullptr, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C, C, 1, 3, 1, planes, st, -1, 0, 0,
+                                 fold_in2, C / 2, wt->down_w[s - 1], wt->down_b[s - 1]);
+                prof_close(st, pi_);
+                if (rc) return rc;
+                x_split = false;
+            } else if (b == 1 && can_split(s)) {       // the stage's output feeds only the next stage's stride-2 entry
                 out = ws + p.buf[s][3];
                 PROF_CONV(1, n, H, W, C, C, 9, conv_common(mid, out, resid, wt->conv_w[wi + 1], wt->conv_b[wi + 1], n, H, W, C, C, 1, 3, 1,
                                                             planes, st, -1, 1, pf_alloc_pixels(cap, H / 2, W / 2)));

@@ -131,6 +131,12 @@ struct ConvArgs {
     // 0 = ordinary PF.  out_split_pixels: the epilogue writes `out` phase-split; in_split_pixels: `in` is phase-split.
     long long out_split_pixels, in_split_pixels;
     int mtiles = 0;                      // set by launchers whose grid is rounded up: number of real pixel tiles
+    // Extra K segment of a stride-1 3x3 conv (mode 3, wide kernel): the 1x1 stride-2 downsample branch of a strided
+    // BasicBlock (resnets_shift.py:173-177) computed INSIDE the block's second conv - `in2` = phase 00 of the block input
+    // (a PF tensor of the OUTPUT's pixel geometry with in2_c channels), wpk2 / bias2 its packed 1x1 weights and folded BN bias:
+    // out = relu(conv3x3(in) + bias + conv1x1(in2) + bias2), no downsample tensor, no residual read.  null = none.
+    const void* in2 = nullptr;
+    int in2_c = 0;
 };
 
 // ConvArgs.flags.  Product flags first; the CONV_ABL_* / study ones only act in builds with -DWSI_STUDY (bottleneck

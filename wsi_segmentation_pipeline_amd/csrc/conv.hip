@@ -448,6 +448,53 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         }
     }
     if constexpr (PLANES == 3) {
+        if (a.in2) {
+            // Extra K segment (common.h ConvArgs.in2): the strided block's 1x1 downsample of the block input, one centre tap per
+            // 32-channel line of `in2` (same pixel geometry as the output: the same slab shape and offsets), accumulated on top
+            // of the 3x3 conv; its BN bias joins the accumulators here.
+            const int NC2 = a.in2_c / 32;
+            const size_t ps2 = (size_t)a.in2_c * 4, sb2 = (size_t)slab0 * ps2;
+            const size_t bytes2 = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * ps2;
+            const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)a.in2 + sb2), 0, (int)min(bytes2 - sb2, (size_t)0x7fffffff), 0x00020000);
+            int xvoff2;
+            {
+                const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+                xvoff2 = Pl * (int)ps2 + sl * 16;
+            }
+            const char* wsrc2 = (const char*)a.wpk2 + (size_t)(nb * NTILES) * NC2 * 4096 + (size_t)(tid & 255) * 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 b2[1];
+                acc_init_bias<1>(b2, a.bias2, nb * NTILES + wn * NT + nt, lane);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][mt][r] += b2[0][r];
+            }
+            for (int c = 0; c < NC2; ++c) {
+                __syncthreads();                              // slab and weight buffers are free again
+                for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
+                    dma16_buf(xrs2, xl + (size_t)i0 * 16, xvoff2, c * 128 + r * (NTHREADS / 8) * (int)ps2);
+#pragma unroll
+                for (int p0 = 0; p0 < NTILES * 256; p0 += NTHREADS) {
+                    const int pw = p0 + wave * 64;
+                    dma16(wsrc2 + (size_t)((pw >> 8) * NC2 + c) * 4096, wl + pw * 16);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                bf16x8 wf2[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wread(wf2[nt], wl, nt);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    bf16x8 x2[4];
+                    xload(x2, xoff[mt] + P + 1);              // the centre tap
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(acc[nt][mt], wf2[nt], x2);
+                }
+            }
+        }
         if (a.resid) __syncthreads();                         // weight stages + slab become the waves' residual staging (NBUF tiles each)
         conv_tail_mx<NT, MT, RESID_NBUF>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096), slab0);
     } else {
@@ -682,13 +729,12 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
 // phase 00: tap (1,1) + the downsample tap; 01: (1,0) (1,2); 10: (0,1) (2,1); 11: (0,0) (0,2) (2,0) (2,2).  The
 // next item's pixels are fetched while the current one multiplies (two slab buffers); waves 0-3 issue the pixel
 // DMA, waves 4-7 the weight DMA, so each wave's in-order vmcnt tracks one kind only.  One barrier per tap.
-template <int PLANES, bool DENSE>
+template <int PLANES, bool DENSE, bool DS>
 __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 2, NT = 2, BM = 256;
     constexpr int WBUF = 16384, XB = 45056;                   // X: up to 352 pixels (256 real ones + their pads + P + 1), whole DMA rounds
-    constexpr int NWB = 4;                                    // weight ring: tap g+3 is requested while tap g multiplies, so a
-                                                              // stage has three steps (not one) to arrive from L2
+    constexpr int NWB = 4;                                    // weight ring: the next unit (<= 2 steps) is requested while this one multiplies
     char* const wl = smem;                                    // NWB weight buffers
     char* const xl0 = smem + NWB * WBUF;                      // 2 pixel buffers
     const int tid = threadIdx.x, lane = tid & 63;
@@ -733,7 +779,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.wpk + (size_t)(nb * 4) * NC * 9 * 4096), 0, 4 * NC * 9 * 4096, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)a.wpk2 + (size_t)(nb * 4) * NC * 4096), 0, 4 * NC * 4096, 0x00020000);
+        (void*)((const char*)(DS ? a.wpk2 : a.wpk) + (size_t)(nb * 4) * NC * 4096), 0, 4 * NC * 4096, 0x00020000);
     const int wvoff = lane * 16;
     // weights of (line c, tap t; t == 9: downsample) -> buffer wb; wave w in 4..7 moves quarter w-4 of each channel tile
     auto wdma = [&](int c, int t, char* wb) {
@@ -763,37 +809,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         }
     };
 
-    f32x16 acc[NT][MT], accd[NT][MT];
+    f32x16 acc[NT][MT], accd[DS ? NT : 1][DS ? MT : 1];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if constexpr (PLANES == 3) {                           // mode 3: accumulators start from the folded BN bias
             acc_init_bias<MT>(acc[nt], a.bias, nb * 4 + wn * 2 + nt, lane);
-            acc_init_bias<MT>(accd[nt], a.bias2, nb * 4 + wn * 2 + nt, lane);
+            if constexpr (DS) acc_init_bias<MT>(accd[nt], a.bias2, nb * 4 + wn * 2 + nt, lane);
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[nt][mt][r] = 0.f; accd[nt][mt][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) {
+                    acc[nt][mt][r] = 0.f;
+                    if constexpr (DS) accd[nt][mt][r] = 0.f;
+                }
         }
     }
 
-    // per-phase tap lists: {3x3 tap index (9 = downsample), LDS pixel shift in units of (1, P)}
-    constexpr int NTAP[4] = {2, 2, 2, 4};
-    constexpr int TAPS[4][4] = {{4, 9, 0, 0}, {3, 5, 0, 0}, {1, 7, 0, 0}, {0, 2, 6, 8}};
-    constexpr int SH1[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 0, 0}, {0, 1, 0, 1}};   // + 1 pixel
-    constexpr int SHP[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 1}};   // + P pixels
-
-    // steps in execution order within a line: (phase, tap); step g of the whole K loop = line g / 10, entry g % 10
-    constexpr int STEP_TAP[10] = {4, 9, 3, 5, 1, 7, 0, 2, 6, 8};
-    const int NG = NC * 10;
-    auto wdma_step = [&](int c, int j) {                      // j may run past 9: wraps into the next line
-        const int cc = c + j / 10, g = cc * 10 + j % 10;
-        if (g < NG) wdma(cc, STEP_TAP[j % 10], wl + (g & (NWB - 1)) * WBUF);
+    // Steps of one 32-channel line in execution order: (phase, 3x3 tap; tap 9 = the fused 1x1 downsample, which reads the
+    // centre pixels = phase 00).  Phase 00: tap (1,1) [+ downsample]; 01: (1,0) (1,2); 10: (0,1) (2,1); 11: the four corners.
+    // The LDS pixel shift of tap (kh, kw) inside its phase buffer is (kw == 2) + (kh == 2) * P.  Steps run in UNITS of one or two
+    // between barriers; the weights of the next unit are requested at the start of the current one and waited for at its end
+    // (ring of four buffers indexed by the running step number: at most two units are alive).
+    constexpr int SPL = DS ? 10 : 9;                                         // steps per line
+    constexpr int STEP_TAP[10] = {4, DS ? 9 : 3, DS ? 3 : 5, DS ? 5 : 1, DS ? 1 : 7, DS ? 7 : 0, DS ? 0 : 2, DS ? 2 : 6, DS ? 6 : 8, 8};
+    constexpr int UNIT0[4] = {0, DS ? 2 : 1, DS ? 4 : 3, DS ? 6 : 5};        // first step of each phase
+    constexpr int NSTEP[4] = {DS ? 2 : 1, 2, 2, 4};
+    const int NG = NC * SPL;
+    auto wdma_step = [&](int c, int j) {                      // j may run past the line: wraps into the next one
+        const int cc = c + j / SPL, g = cc * SPL + j % SPL;
+        if (g < NG) wdma(cc, STEP_TAP[j % SPL], wl + (g & (NWB - 1)) * WBUF);
     };
-    // Steps run in PAIRS (two taps of one phase) between barriers: the ring's four buffers are two pair slots; the weights
-    // of pair p+1 are requested at the start of pair p (a pair = 24 MFMAs per wave of lead) and waited for at its end.
     if (wave < 4) xdma(0, 0, xl0);
-    else { wdma_step(0, 0); wdma_step(0, 1); }
+    else { wdma_step(0, 0); if (NSTEP[0] == 2) wdma_step(0, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < NC; ++c) {
@@ -805,17 +853,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 else if (c + 1 < NC) xdma(c + 1, 0, xl0);
             }
 #pragma unroll
-            for (int kp = 0; kp < NTAP[ph]; kp += 2) {
-                constexpr int J0[4] = {0, 2, 4, 6};
-                const int j0 = J0[ph] + kp;                   // first step of the pair (even)
-                if (wave >= 4) { wdma_step(c, j0 + 2); wdma_step(c, j0 + 3); }   // the next pair
+            for (int kp = 0; kp < NSTEP[ph]; kp += 2) {
+                const int j0 = UNIT0[ph] + kp;                // first step of the unit
+                const int ulen = NSTEP[ph] - kp >= 2 ? 2 : 1;
+                // the next unit: the rest of this phase, or the first unit of the next phase / line
+                const int jn = j0 + ulen;
+                const int nlen = (kp + 2 < NSTEP[ph]) ? 2 : (ph < 3 ? (NSTEP[ph + 1] >= 2 ? 2 : 1) : (NSTEP[0] >= 2 ? 2 : 1));
+                if (wave >= 4) { wdma_step(c, jn); if (nlen == 2) wdma_step(c, jn + 1); }
 #pragma unroll
-                for (int k = kp; k < kp + 2; ++k) {
-                    const int g = c * 10 + J0[ph] + k;
-                    const int t = TAPS[ph][k];
+                for (int k = 0; k < ulen; ++k) {
+                    const int g = c * SPL + j0 + k;
+                    const int t = STEP_TAP[j0 + k];
                     bf16x8 wf[NT][4], xf[MT][4];
                     wread(wf, wl + (g & (NWB - 1)) * WBUF);
-                    const int sh = SH1[ph][k] + SHP[ph][k] * P;
+                    const int sh = (t < 9 && t % 3 == 2 ? 1 : 0) + (t < 9 && t / 3 == 2 ? P : 0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         int ql = qs[mt] - q0;
@@ -828,11 +879,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if constexpr (DS) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
+                            else mfma_step<PLANES>(acc[nt][mt], wf[nt], xf[mt]);
+                        }
                 }
-                // end of the pair: the weight waves wait for the next pair's stages, the pixel waves (at an item's last pair)
+                // end of the unit: the weight waves wait for the next unit's stages, the pixel waves (at an item's last unit)
                 // for the next item's pixels
-                if (wave >= 4 || kp + 2 == NTAP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (wave >= 4 || kp + 2 >= NSTEP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
         }
@@ -840,14 +894,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int ntile = nb * 4 + wn * 2 + nt;
-        ConvArgs a2 = a;
-        a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
         if constexpr (PLANES == 3) {
             conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
-            conv_epilogue_mx<MT>(a2, accd[nt], qs, valid, ntile, lane);
         } else {
             conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, ntile, lane);
-            conv_epilogue_q<MT, PLANES>(a2, accd[nt], qs, valid, ntile, lane);
+        }
+        if constexpr (DS) {
+            ConvArgs a2 = a;
+            a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
+            if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a2, accd[nt], qs, valid, ntile, lane);
+            else conv_epilogue_q<MT, PLANES>(a2, accd[nt], qs, valid, ntile, lane);
         }
     }
 }
@@ -855,7 +911,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
 template <int PLANES>
 static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256, XB = 45056;
-    if (a.go.C % 128 || a.go.P > 34 || !a.in_split_pixels || !a.out2 || !a.wpk2 || !a.bias2 || a.out_split_pixels) return WSI_EINVAL;
+    const bool ds = a.out2 != nullptr;                                       // fused 1x1 downsample branch, or the 3x3 conv alone
+    if (a.go.C % 128 || a.go.P > 34 || !a.in_split_pixels || (ds && (!a.wpk2 || !a.bias2)) || a.out_split_pixels) return WSI_EINVAL;
     const long long R = (long long)a.go.N * a.go.H * a.go.W;
     const int nblocks = a.go.C / 128;
     // dense tiles if the span of 256 real pixels (+ the largest phase back-shift) fits one pixel buffer
@@ -865,7 +922,8 @@ static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
     const bool dense = (span * 8 + 255) / 256 * 256 * 16 <= XB;
     const int mtiles = dense ? (int)((R + BM - 1) / BM) : (a.go.NS + BM - 1) / BM;
     const size_t lds = 4 * 16384 + 2 * XB;
-    auto k = dense ? conv3x3s2_wide_kernel<PLANES, true> : conv3x3s2_wide_kernel<PLANES, false>;
+    auto k = dense ? (ds ? conv3x3s2_wide_kernel<PLANES, true, true> : conv3x3s2_wide_kernel<PLANES, true, false>)
+                   : (ds ? conv3x3s2_wide_kernel<PLANES, false, true> : conv3x3s2_wide_kernel<PLANES, false, false>);
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
     ConvArgs b = a;
     b.mtiles = mtiles;
