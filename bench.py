@@ -304,7 +304,7 @@ def run_rank(args):
                     'traffic': pmc_bytes(('conv3x3s1_wide', 'conv3x3s1_pp'), eff_batch),
                     'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                     'traffic_source': ('%s: rocprofv3 --pmc passes of this command at batch %s, scaled to this run\'s batch of %d (not measured in this run)' %
-                                       (os.path.relpath(tpath, ROOT), tj.get('batch', 1000), eff_batch)) if tj else 'not collected for this mode',
+                                       (os.path.relpath(tpath, ROOT), tj.get('batch', 1000), eff_batch or 0)) if tj else 'not collected for this mode',
                     'avg_launch_ms': round(k['avg_ms'], 4), 'mfma_passes': passes[planes], 'precision_mode': args.mode}
     l1 = per_kind.get('layer1_block_fused') or per_kind.get('conv3x3_s1_layer1')
     if l1 and eff_batch:
