@@ -238,6 +238,14 @@ int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, do
 size_t wsi_connected_components_scratch_bytes(int h, int w);
 int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream);
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream);
+/* utils/preprocessing.py:88-92 find_nuclei(mode='lab'): mask = a > (1 + mu_percent) * mean(a), a = the second channel of skimage's
+ * rgb2lab (own deterministic spec: a in 2^-20 fixed point, exact mean; parity unpinned).  scratch: 16 + 4 * npix bytes.
+ * utils/preprocessing.py:101-106 fill_mask: wsi_fill_holes = scipy.ndimage.binary_fill_holes (background components, 4-connected,
+ * that touch no border are filled; synchronises the stream like wsi_connected_components); the 10x10 close that follows is two
+ * wsi_morph_rect calls (dilate, erode). */
+int wsi_find_nuclei_lab(const uint8_t* rgb, long long npix, int pixel_stride, double mu_percent, uint8_t* mask_out, void* scratch, void* stream);
+size_t wsi_fill_holes_scratch_bytes(int h, int w);
+int wsi_fill_holes(const uint8_t* mask, int h, int w, uint8_t* out, void* scratch, void* stream);
 /* slic.py:43 skimage.segmentation.slic(img_as_float(rgb), n_segments, compactness, sigma, enforce_connectivity=False) on a 2-D RGB
  * thumbnail, as an own deterministic specification of the published algorithm (skimage is absent: parity unpinned;
  * oracle/proposals_oracle.py slic_labels): Gaussian filter with the caller's 2 radius + 1 float64 weights (scipy.ndimage order,

@@ -34,6 +34,27 @@ def find_nuclei_hsv(rgb_u8, mu_percent=0.1):
     return (s > mu_percent).astype(np.uint8)
 
 
+def find_nuclei_lab(rgb_u8, mu_percent=0.1):
+    """/root/reference/utils/preprocessing.py:88-92 (mode='lab'): a = skimage rgb2lab(image)[..., 1]; mask = a > (1 + mu_percent) *
+    mean(a).  skimage is absent (parity unpinned): rgb2lab restated (oracle/proposals_oracle.py) and, to make the mean independent
+    of the summation order, `a` is rounded to 2^-20 fixed point: mean = (exact integer sum / 2^20) / count."""
+    from .proposals_oracle import rgb2lab
+    a = rgb2lab(np.asarray(rgb_u8)[..., :3].astype(np.float64) / 255.0)[..., 1]
+    aq = np.rint(a * 1048576.0).astype(np.int64)
+    mu = (float(int(aq.sum())) / 1048576.0) / float(aq.size)
+    return ((aq.astype(np.float64) / 1048576.0) > (1 + mu_percent) * mu).astype(np.uint8)
+
+
+def fill_mask(mask, kernel_size=10):
+    """/root/reference/utils/preprocessing.py:101-106: scipy.ndimage.binary_fill_holes (SciPy itself: pinned) followed by
+    cv2.morphologyEx(MORPH_CLOSE, ones((10, 10))) = erode(dilate(.)) with OpenCV's anchor and border rules
+    (oracle/postprocess_oracle.py, parity unpinned)."""
+    from scipy.ndimage import binary_fill_holes
+    from .postprocess_oracle import dilate_rect, erode_rect
+    filled = binary_fill_holes(np.asarray(mask) != 0).astype(np.uint8)
+    return erode_rect(dilate_rect(filled, kernel_size), kernel_size).astype(np.uint8)
+
+
 def tile_grid(iw, ih, ph, pw, sh, sw, mask=None, m=1.0, thresh=0.05):
     """/root/reference/utils/dataset.py:143-166.  Returns [(xpos, ypos)] in the reference's order:
     interior raster, then the right-edge column, then the bottom-edge row (no corner tile).

@@ -154,3 +154,31 @@ def test_slic_candidates_metadata_exact(P):
     for k in meta:
         assert np.array_equal(meta[k]['cnt_xy'], rm[k]['cnt_xy']) and np.array_equal(meta[k]['perim_xy'], rm[k]['perim_xy'])
         assert all(np.array_equal(a, b) for a, b in zip(meta[k]['foreground_indices'], rm[k]['foreground_indices']))
+
+
+# ------------------------------------------------------------------------------ find_nuclei, the non-default modes
+def test_find_nuclei_lab_and_fill_mask_exact(P):
+    """preprocessing.find_nuclei(mode='lab') and fill_mask=True (/root/reference/utils/preprocessing.py:88-92,101-106) on the
+    device against the oracle (rgb2lab restated, SciPy's binary_fill_holes itself, the cv2 close restated)."""
+    from tests.test_proposals_oracle import _thumb
+    from oracle import wsi_oracle as WO
+    from utils import preprocessing
+    for seed, hw in ((0, (150, 201)), (3, (97, 64))):
+        img = _thumb(seed, hw)
+        img[10:40, 20:60] = (180, 60, 150)                                          # purple block: high a
+        g = torch.from_numpy(img).cuda()
+        for mu in (0.1, 0.5):
+            assert np.array_equal(P.find_nuclei_lab(g, mu).cpu().numpy(), WO.find_nuclei_lab(img, mu))
+        assert np.array_equal(preprocessing.find_nuclei(g, mode='lab').cpu().numpy(), WO.find_nuclei_lab(img))
+    rng = np.random.default_rng(5)
+    for hw in ((120, 160), (64, 64), (33, 130)):
+        m = (rng.random(hw) < 0.08).astype(np.uint8)
+        yy, xx = np.mgrid[:hw[0], :hw[1]]
+        ring = (np.abs(np.hypot(yy - hw[0] / 2, xx - hw[1] / 2) - min(hw) / 3) < 2.5).astype(np.uint8)   # a closed ring: its inside is a hole
+        m |= ring
+        m[:, 0] = 0
+        got = P.fill_mask(torch.from_numpy(m).cuda()).cpu().numpy()
+        ref = WO.fill_mask(m)
+        assert np.array_equal(got, ref) and ref.sum() > m.sum() + 20
+    hsv_filled = preprocessing.find_nuclei(torch.from_numpy(_thumb(2, (90, 120))).cuda(), fill_mask=True).cpu().numpy()
+    assert np.array_equal(hsv_filled, WO.fill_mask(WO.find_nuclei_hsv(_thumb(2, (90, 120)))))

@@ -131,3 +131,15 @@ def test_slic_labels_properties(seed, hw, nseg, sigma):
     assert labels.shape == (hw[0] * 2, hw[1] * 2) and len(meta) >= 0.5 * len(np.unique(lab))
     for k, r in meta.items():
         assert r['cnt_xy'].shape == (3, 2) and r['perim_xy'].shape[1] == 2 and (labels[r['foreground_indices']] == k).all()
+
+
+def test_find_nuclei_lab_and_fill_mask_oracle():
+    from oracle import wsi_oracle as WO
+    img = _thumb(4, (60, 80))
+    img[5:25, 10:40] = (180, 60, 150)
+    m = WO.find_nuclei_lab(img)
+    assert m.dtype == np.uint8 and m[10, 20] == 1 and 0 < m.mean() < 0.9
+    ring = np.zeros((40, 40), np.uint8)
+    ring[8:30, 8] = ring[8:30, 29] = ring[8, 8:30] = ring[29, 8:30] = 1
+    f = WO.fill_mask(ring)
+    assert f[18, 18] == 1 and f[2, 2] == 0 and f.sum() >= 22 * 22

@@ -31,14 +31,18 @@ def isforeground(arr, thresh=0.05):
 
 
 def find_nuclei(wsi, mu_percent=0.1, mode='hsv', fill_mask=False):
-    """Foreground mask of a thumbnail: HSV saturation > mu_percent (u8 mask of 0/1).
-    S = (max - min) / max on the [0,1]-scaled RGB values, 0 where max == min (scikit-image's
-    rgb2hsv definition, which the reference calls)."""
-    if mode != 'hsv' or fill_mask:
-        raise NotImplementedError("only mode='hsv', fill_mask=False (the eval-path configuration) is provided")
-    if torch.is_tensor(wsi) and wsi.is_cuda:                       # device thumbnails stay on the device (wsi_find_nuclei_hsv)
+    """Foreground mask of a thumbnail (u8 mask of 0/1).  mode 'hsv' (the eval scripts' default): HSV saturation > mu_percent, S =
+    (max - min) / max on the [0,1]-scaled RGB values, 0 where max == min (scikit-image's rgb2hsv definition, which the reference
+    calls).  mode 'lab' (:88-92) and fill_mask (:101-106: fill holes, 10x10 close) run on the device for CUDA thumbnails
+    (wsi_find_nuclei_lab, wsi_fill_holes + wsi_morph_rect; own deterministic spec of the absent skimage / cv2: parity unpinned)."""
+    if mode not in ('hsv', 'lab'):
+        raise ValueError("mode must be 'hsv' or 'lab'")
+    if torch.is_tensor(wsi) and wsi.is_cuda:                       # device thumbnails stay on the device
         from wsi_segmentation_pipeline_amd import proposals as P
-        return P.find_nuclei(wsi, mu_percent)
+        mask = P.find_nuclei(wsi, mu_percent) if mode == 'hsv' else P.find_nuclei_lab(wsi, mu_percent)
+        return P.fill_mask(mask) if fill_mask else mask
+    if mode != 'hsv' or fill_mask:
+        raise NotImplementedError("host arrays: only mode='hsv', fill_mask=False; pass a CUDA tensor for mode='lab' / fill_mask")
     rgb = np.asarray(wsi)[..., :3].astype(np.float64) / 255.0
     hi, lo = rgb.max(-1), rgb.min(-1)
     delta = hi - lo

@@ -26,7 +26,10 @@ int wsi_paint_dispatch(const long long* idx, const int* region_of, long long n, 
                        long long npix, hipStream_t st);
 int wsi_hsv_mask_dispatch(const uint8_t* rgb, long long npix, int stride, double thresh, uint8_t* mask, hipStream_t st);
 size_t wsi_cc_scratch_bytes(int H, int W);
-int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* count_out, void* scratch, hipStream_t st);
+int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* count_out, void* scratch, hipStream_t st, int conn4 = 0);
+int wsi_lab_mask_dispatch(const uint8_t* rgb, long long npix, int stride, double mu_percent, uint8_t* mask, void* scratch, hipStream_t st);
+size_t wsi_fill_holes_scratch_bytes_impl(int H, int W);
+int wsi_fill_holes_dispatch(const uint8_t* mask, int H, int W, uint8_t* out, void* scratch, hipStream_t st);
 int wsi_kmeans_dispatch(const int* pts, int n, double* centres, int k, int iters, int* labels, void* scratch, hipStream_t st);
 int wsi_exponent_span_dispatch(const float* v, long long n, int* out2, hipStream_t st);
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
@@ -566,6 +569,13 @@ size_t wsi_connected_components_scratch_bytes(int h, int w) { return (h <= 0 || 
 int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream) {
     if (!mask || !labels_out || !scratch) return WSI_EINVAL;
     return wsi_cc_dispatch(mask, h, w, labels_out, count_out, scratch, (hipStream_t)stream);
+}
+int wsi_find_nuclei_lab(const uint8_t* rgb, long long npix, int pixel_stride, double mu_percent, uint8_t* mask_out, void* scratch, void* stream) {
+    return wsi_lab_mask_dispatch(rgb, npix, pixel_stride, mu_percent, mask_out, scratch, (hipStream_t)stream);
+}
+size_t wsi_fill_holes_scratch_bytes(int h, int w) { return (h <= 0 || w <= 0) ? 0 : wsi_fill_holes_scratch_bytes_impl(h, w); }
+int wsi_fill_holes(const uint8_t* mask, int h, int w, uint8_t* out, void* scratch, void* stream) {
+    return wsi_fill_holes_dispatch(mask, h, w, out, scratch, (hipStream_t)stream);
 }
 size_t wsi_slic_scratch_bytes(int h, int w, int k) { return wsi_slic_scratch_bytes_impl(h, w, k); }
 int wsi_slic(const uint8_t* rgb, int h, int w, const double* gauss_weights, int radius, double* segments, int k, int step_y, int step_x,

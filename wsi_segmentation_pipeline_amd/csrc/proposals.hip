@@ -31,15 +31,16 @@ static __device__ inline int cc_find(const int* L, int a) {
 __global__ __launch_bounds__(256) void cc_init_kernel(const uint8_t* mask, int* L, long long n) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) L[i] = mask[i] ? (int)i + 1 : 0;
 }
-__global__ __launch_bounds__(256) void cc_merge_kernel(int* L, int H, int W, int* changed) {
+__global__ __launch_bounds__(256) void cc_merge_kernel(int* L, int H, int W, int* changed, int conn4) {
     const long long n = (long long)H * W;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         if (!L[i]) continue;
         const int y = (int)(i / W), x = (int)(i % W);
         int ra = cc_find(L, (int)i);
-        // the four already-scanned 8-neighbours (the other four are covered from their side)
+        // the four already-scanned 8-neighbours (the other four are covered from their side); 4-connectivity: up and left only
         const int dy[4] = {-1, -1, -1, 0}, dx[4] = {-1, 0, 1, -1};
         for (int k = 0; k < 4; ++k) {
+            if (conn4 && (k == 0 || k == 2)) continue;
             const int yy = y + dy[k], xx = x + dx[k];
             if (yy < 0 || xx < 0 || xx >= W) continue;
             const long long q = (long long)yy * W + xx;
@@ -129,6 +130,70 @@ __global__ void kmeans_update_kernel(double* centres, int k, const unsigned long
         centres[2 * j] = (double)(long long)sums[3 * j] / (double)c;
         centres[2 * j + 1] = (double)(long long)sums[3 * j + 1] / (double)c;
     }
+}
+
+// ------------------------------------------------------------------------------------------ find_nuclei, the other modes
+// mode 'lab' (/root/reference/utils/preprocessing.py:88-92): a = rgb2lab(image)[..., 1]; mask = a > (1 + mu_percent) * mean(a).
+// skimage is absent: own deterministic specification (oracle/wsi_oracle.py find_nuclei_lab) - `a` in 2^-20 fixed point so that the
+// mean is an exact integer sum / count.  Two kernels: a -> int32 + sum; threshold.
+#define LAB_FIX 1048576.0
+static __device__ __forceinline__ double lab_a_of_rgb(const uint8_t* p) {
+    double v[3], f[2];
+    for (int c = 0; c < 3; ++c) {
+        const double a = (double)p[c] / 255.0;
+        v[c] = a > 0.04045 ? pow((a + 0.055) / 1.055, 2.4) : a / 12.92;
+    }
+    const double M[2][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}};
+    const double white[2] = {0.95047, 1.0};
+    for (int r = 0; r < 2; ++r) {
+        double t = v[0] * M[r][0];
+        t += v[1] * M[r][1];
+        t += v[2] * M[r][2];
+        t = t / white[r];
+        f[r] = t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0;
+    }
+    return 500.0 * (f[0] - f[1]);
+}
+__global__ __launch_bounds__(256) void lab_a_kernel(const uint8_t* rgb, long long npix, int stride, int* aq, unsigned long long* sum) {
+    long long s = 0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const int q = (int)llrint(lab_a_of_rgb(rgb + i * stride) * LAB_FIX);
+        aq[i] = q;
+        s += q;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(sum, (unsigned long long)s);
+}
+__global__ __launch_bounds__(256) void lab_thresh_kernel(const int* aq, long long npix, const unsigned long long* sum, double mu_percent, uint8_t* mask) {
+    const double mu = ((double)(long long)*sum / LAB_FIX) / (double)npix;
+    const double thr = (1 + mu_percent) * mu;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (long long)gridDim.x * 256)
+        mask[i] = ((double)aq[i] / LAB_FIX > thr) ? 1 : 0;
+}
+// binary_fill_holes (scipy.ndimage, default structure = 4-connectivity of the BACKGROUND): background components that touch
+// no image border are holes.  labels = 4-connected components of the inverted mask (wsi_cc_dispatch conn4); touch[label] = 1 for
+// labels on the border; out = mask | (label && !touch[label]).
+__global__ __launch_bounds__(256) void holes_touch_kernel(const int* labels, int H, int W, int* touch) {
+    const int n = 2 * (H + W);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int y, x;
+        if (i < W) { y = 0; x = i; }
+        else if (i < 2 * W) { y = H - 1; x = i - W; }
+        else if (i < 2 * W + H) { y = i - 2 * W; x = 0; }
+        else { y = i - 2 * W - H; x = W - 1; }
+        const int l = labels[(size_t)y * W + x];
+        if (l) touch[l] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void holes_fill_kernel(const uint8_t* mask, const int* labels, const int* touch, long long n, uint8_t* out) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (mask[i] || (labels[i] && !touch[labels[i]])) ? 1 : 0;
+}
+size_t wsi_cc_scratch_bytes(int H, int W);
+size_t wsi_fill_holes_scratch_bytes_impl(int H, int W) {
+    const size_t n = (size_t)H * W;
+    return wsi_cc_scratch_bytes(H, W) + n /* inverted mask */ + 2 * (n + 2) * sizeof(int) /* labels, touch */ + 512;
 }
 
 // ------------------------------------------------------------------------------------------ SLIC superpixels
@@ -340,6 +405,17 @@ static int grid_for(long long total) {
 }
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT)
 
+// scratch: npix int32 + one u64 (zeroed here)
+int wsi_lab_mask_dispatch(const uint8_t* rgb, long long npix, int stride, double mu_percent, uint8_t* mask, void* scratch, hipStream_t st) {
+    if (!rgb || !mask || !scratch || npix <= 0 || stride < 3) return WSI_EINVAL;
+    unsigned long long* sum = (unsigned long long*)scratch;
+    int* aq = (int*)(sum + 2);
+    if (hipMemsetAsync(sum, 0, 16, st) != hipSuccess) return WSI_EFAULT;
+    const int g = grid_for(npix) > 2048 ? 2048 : grid_for(npix);
+    hipLaunchKernelGGL(lab_a_kernel, dim3(g), dim3(256), 0, st, rgb, npix, stride, aq, sum);
+    hipLaunchKernelGGL(lab_thresh_kernel, dim3(g), dim3(256), 0, st, (const int*)aq, npix, (const unsigned long long*)sum, mu_percent, mask);
+    return LAUNCH_OK();
+}
 int wsi_hsv_mask_dispatch(const uint8_t* rgb, long long npix, int stride, double thresh, uint8_t* mask, hipStream_t st) {
     if (npix <= 0 || stride < 3) return WSI_EINVAL;
     hipLaunchKernelGGL(hsv_mask_kernel, dim3(grid_for(npix)), dim3(256), 0, st, rgb, npix, stride, thresh, mask);
@@ -351,7 +427,7 @@ size_t wsi_cc_scratch_bytes(int H, int W) {
     const long long n = (long long)H * W, nb = (n + 1023) / 1024;
     return (size_t)(3 * n + nb + 4) * sizeof(int);
 }
-int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* count_out, void* scratch, hipStream_t st) {
+int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* count_out, void* scratch, hipStream_t st, int conn4) {
     if (H <= 0 || W <= 0 || (long long)H * W > 0x7ffffff0LL) return WSI_EINVAL;
     const long long n = (long long)H * W, nb = (n + 1023) / 1024;
     int* L = (int*)scratch;
@@ -361,7 +437,7 @@ int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* cou
     // union-find with atomic hooks converges in one sweep for most images; sweep until a pass changes nothing (bounded)
     for (int it = 0; it < 64; ++it) {
         if (hipMemsetAsync(misc, 0, sizeof(int), st) != hipSuccess) return WSI_EFAULT;
-        hipLaunchKernelGGL(cc_merge_kernel, dim3(g), dim3(256), 0, st, L, H, W, misc);
+        hipLaunchKernelGGL(cc_merge_kernel, dim3(g), dim3(256), 0, st, L, H, W, misc, conn4);
         int changed = 0;
         if (hipMemcpyAsync(&changed, misc, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return WSI_EFAULT;
         if (!changed) break;
@@ -371,6 +447,27 @@ int wsi_cc_dispatch(const uint8_t* mask, int H, int W, int* labels_out, int* cou
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, bsum, (int)nb, misc + 1);
     hipLaunchKernelGGL(cc_rank_kernel, dim3(g), dim3(256), 0, st, (const int*)L, (const int*)excl, (const int*)bsum, n, labels_out);
     if (count_out && hipMemcpyAsync(count_out, misc + 1, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return WSI_EFAULT;
+    return LAUNCH_OK();
+}
+
+__global__ __launch_bounds__(256) void invert_mask_kernel(const uint8_t* m, long long n, uint8_t* o) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = m[i] ? 0 : 1;
+}
+int wsi_fill_holes_dispatch(const uint8_t* mask, int H, int W, uint8_t* out, void* scratch, hipStream_t st) {
+    if (!mask || !out || !scratch || H <= 0 || W <= 0) return WSI_EINVAL;
+    const long long n = (long long)H * W;
+    char* p = (char*)scratch;
+    void* cc = p; p += (wsi_cc_scratch_bytes(H, W) + 255) / 256 * 256;
+    int* labels = (int*)p; p += (n + 2) * sizeof(int);
+    int* touch = (int*)p; p += (n + 2) * sizeof(int);
+    uint8_t* inv = (uint8_t*)p;
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(invert_mask_kernel, dim3(g), dim3(256), 0, st, mask, n, inv);
+    const int rc = wsi_cc_dispatch(inv, H, W, labels, nullptr, cc, st, 1);
+    if (rc) return rc;
+    if (hipMemsetAsync(touch, 0, (size_t)(n + 2) * sizeof(int), st) != hipSuccess) return WSI_EFAULT;
+    hipLaunchKernelGGL(holes_touch_kernel, dim3((2 * (H + W) + 255) / 256), dim3(256), 0, st, (const int*)labels, H, W, touch);
+    hipLaunchKernelGGL(holes_fill_kernel, dim3(g), dim3(256), 0, st, mask, (const int*)labels, (const int*)touch, n, out);
     return LAUNCH_OK();
 }
 

@@ -90,6 +90,9 @@ SIGNATURES = {
     'wsi_connected_components_scratch_bytes': (_sz, [_i, _i]),
     'wsi_connected_components': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     'wsi_kmeans_points': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'wsi_find_nuclei_lab': (_i, [_vp, _ll, _i, _d, _vp, _vp, _vp]),
+    'wsi_fill_holes_scratch_bytes': (_sz, [_i, _i]),
+    'wsi_fill_holes': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'wsi_slic_scratch_bytes': (_sz, [_i, _i, _i]),
     'wsi_slic': (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
     'wsi_tile_grid_candidates': (_ll, [_i, _i, _i, _i, _i, _i]),

@@ -29,6 +29,32 @@ def find_nuclei(rgb_u8, mu_percent=0.1):
     return mask
 
 
+def find_nuclei_lab(rgb_u8, mu_percent=0.1):
+    """reference find_nuclei(mode='lab') on the device: Lab `a` channel above (1 + mu_percent) x its mean (wsi_find_nuclei_lab)."""
+    lib = native.load()
+    _require_gpu(rgb_u8, 'thumbnail')
+    if rgb_u8.dtype != torch.uint8 or rgb_u8.dim() != 3 or rgb_u8.shape[2] < 3:
+        raise ValueError('expected an (H,W,3) uint8 image')
+    img = rgb_u8.contiguous()
+    h, w, c = img.shape
+    mask = torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    scratch = torch.empty(16 + 4 * h * w, dtype=torch.uint8, device=img.device)
+    native.check(lib.wsi_find_nuclei_lab(_ptr(img), h * w, c, float(mu_percent), _ptr(mask), _ptr(scratch), _stream()), 'wsi_find_nuclei_lab')
+    return mask
+
+
+def fill_mask(mask, kernel_size=10):
+    """reference find_nuclei(fill_mask=True) tail on the device: binary_fill_holes (wsi_fill_holes) + MORPH_CLOSE kernel_size^2."""
+    lib = native.load()
+    _require_gpu(mask, 'mask')
+    m = (mask != 0).to(torch.uint8).contiguous()
+    h, w = m.shape
+    out = torch.empty_like(m)
+    scratch = torch.empty(lib.wsi_fill_holes_scratch_bytes(h, w), dtype=torch.uint8, device=m.device)
+    native.check(lib.wsi_fill_holes(_ptr(m), h, w, _ptr(out), _ptr(scratch), _stream()), 'wsi_fill_holes')
+    return PP.morph_rect(PP.morph_rect(out, kernel_size, 'dilate'), kernel_size, 'erode')
+
+
 def connected_components(mask):
     """uint8 / bool (H,W) GPU mask -> (int32 labels, count): 8-connected, numbered in raster order of first pixels."""
     lib = native.load()
