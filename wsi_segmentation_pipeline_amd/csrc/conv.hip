@@ -103,7 +103,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 // lane simply carries its own slab offset.
 // ABL: compile-time ablation for bottleneck studies (tools/tune_conv.py cfg 50-53): 8 = no MFMA, 16 = no weight
 // prefetch (stale registers), 32 = no pixel-fragment LDS reads (stale registers).  0 in every shipped configuration.
-template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0>
+// PAIR (launcher: dense tiles of a map whose width is a multiple of 64, whole tiles only): pixel tile 2j+1 of a wave lies 32
+// pixels to the right of tile 2j in the SAME map row, so its fragments sit exactly 4096 bytes behind tile 2j's in the slab
+// (the slot swizzle has period 16 pixels) - its four LDS reads reuse the even tile's address registers with an immediate
+// offset and cost no address arithmetic (r03: layer 1 spent ~650 of its ~1650 vector instructions per wave on these addresses).
+template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0, bool PAIR = false>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = WM * MT * 32;
@@ -195,10 +199,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         for (int f = 0; f < 4; ++f)
             w[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + f * 1024, soff, 0));
     };
-    auto xload = [&](bf16x8(&x)[4], int Pl) {
+    int xa[4];                                                // fragment addresses of the last even tile (PAIR)
+    auto xload_m = [&](bf16x8(&x)[4], int Pl, int m) {        // m: the tile index (compile-time after unrolling)
+        if (PAIR && (m & 1)) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + xa[f] + 4096);
+            return;
+        }
         const int base = lds_xbase(Pl, h);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+        for (int f = 0; f < 4; ++f) {
+            xa[f] = base ^ (f << 5);
+            x[f] = *(const bf16x8*)(smem + xa[f]);
+        }
     };
 
     for (int c = 0; c < NC; ++c) {
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        xload(xf[0], xoff[0]);                                // step (t=0, mt=0): toff(0) = 0
+        xload_m(xf[0], xoff[0], 0);                           // step (t=0, mt=0): toff(0) = 0
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             asm volatile("" ::: "memory");                    // scheduling fence: keep later taps' loads below
@@ -228,8 +241,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             for (int mt = 0; mt < MT; ++mt) {
                 const int k = t * MT + mt;
                 if constexpr (!(ABL & 32)) {
-                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
-                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                    if (mt + 1 < MT) xload_m(xf[(k + 1) & 1], xoff[mt + 1] + toff, mt + 1);
+                    else if (t < 8) xload_m(xf[(k + 1) & 1], xoff[0] + toff_next, 0);
                 }
                 const bf16x8(&w)[4] = wbuf[t % 3];
                 const bf16x8(&x)[4] = xf[k & 1];
@@ -281,7 +294,7 @@ long long dense_max_slab_pixels(const ConvArgs& a, int BM) {
     return maxpix;
 }
 
-template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0>
+template <int MT, int WM, int WN, int PLANES, int MINW, bool DENSE, int ABL = 0, bool PAIR = false>
 static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * MT * 32, NTHREADS = WM * WN * 64;
     if (a.go.C % (WN * 32)) return WSI_EINVAL;
@@ -298,7 +311,8 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     size_t lds = (size_t)((maxpix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (lds < (size_t)WM * WN * 8192) lds = (size_t)WM * WN * 8192;          // the epilogue stages residual tiles there (8 KB per wave)
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE, ABL>;
+    if (PAIR && (!DENSE || MT % 2 || a.gi.W % 64 || ((long long)a.gi.N * a.gi.H * a.gi.W) % BM)) return WSI_EINVAL;
+    auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE, ABL, PAIR>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return WSI_EINVAL;
@@ -932,6 +946,7 @@ static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
 }
 
 int g_s2_ablate = 0;
+int g_slab_pair = 1;                                     // A/B (wsi_conv_set_mode +4096 off): paired-tile LDS addressing of the layer-1 kernel
 int g_xcd_ranges = 2;                                    // XCD-contiguous tile ranges: 1 = the 64-channel layer only, 2 = every stride-1 layer (r01: ~-1 % overall)
 int g_xcd_order = 0;                                     // 1: CONV_XCD_ORDER for multi-channel-block launches
 int g_s2_small_tiles = 1;                                // r01: 64-pixel tiles measured ~10 % faster (3 workgroups per CU)
@@ -1033,7 +1048,11 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     if (cfg == 30) return planes == 3 ? launch_slab3<4, 1, 4, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 1, 4, 2, 2, true>(a, st) : launch_slab3<4, 1, 4, 1, 2, true>(a, st);
     if (cfg == 31) return planes == 3 ? launch_slab3<4, 2, 2, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<4, 2, 2, 2, 2, true>(a, st) : launch_slab3<4, 2, 2, 1, 2, true>(a, st);
     // cfg 38: cfg 31 held to 168 registers = three waves per SIMD, three workgroups per CU (r03 A/B on layer 1)
-    if (cfg == 38) return planes == 3 ? launch_slab3<4, 2, 2, 3, 3, true>(a, st) : WSI_EINVAL;
+    if (cfg == 38) {
+        if (planes != 3) return WSI_EINVAL;
+        const int rc = g_slab_pair ? launch_slab3<4, 2, 2, 3, 3, true, 0, true>(a, st) : WSI_EINVAL;     // paired-tile addressing where the map allows it
+        return rc != WSI_EINVAL ? rc : launch_slab3<4, 2, 2, 3, 3, true>(a, st);
+    }
     // cfg 39: 512 px x 64 couts (4 x 2 waves) for 64-channel layers on maps wider than 128 (the U-Net decoder's last level): a
     // 256-pixel tile of a 256-wide map is ONE row under a three-row slab; two rows per tile cut the halo from 3x to 2x
     if (cfg == 39) return planes == 3 ? launch_slab3<4, 4, 2, 3, 1, true>(a, st) : planes == 2 ? launch_slab3<4, 4, 2, 2, 1, true>(a, st) : launch_slab3<4, 4, 2, 1, 1, true>(a, st);
