@@ -181,6 +181,11 @@ def test_region_bags_and_paint_match_oracle(dev, sd_full):
     assert np.abs(ens.cpu().numpy() - ens_ref.numpy()).max() <= LOGIT_TOL
     got_mask = val.predict_regions(model, it, metadata, label_shape)
     assert np.array_equal(got_mask, ref_mask)
+    # a plain iterable of (images, tile_ids) batches, like the reference's DataLoader (no .dataset / .shard): single rank only
+    batches = [(b.cpu(), t) for b, t in it]
+    assert np.array_equal(val.predict_regions(model, batches, metadata, label_shape), ref_mask)
+    with pytest.raises(ValueError):
+        val.predict_regions(model, batches, metadata, label_shape, rank=0, world=2)
 
 
 def test_predict_wsis_dense_accumulate_matches_oracle(dev, tmp_path):

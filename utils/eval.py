@@ -265,21 +265,28 @@ def predict_regions(model, iterator, metadata, label_shape, class_probs=None, ra
     ensemble logits are soft-maxed over the class axis): bags -> ResNet bag forward on the HIP path -> class per region ->
     painted label image (int64 ndarray).  With world > 1 (torch.distributed initialised) the bags are sharded over the ranks
     by greedy cost balance, each rank runs its share, ONE all-gather of the (R, C) ensemble logits follows and every rank
-    paints the identical label image on its device (wsi_paint_regions)."""
+    paints the identical label image on its device (wsi_paint_regions).  `iterator`: a utils.dataset_hr.DeviceBagIterator
+    (`.dataset`, `.shard`: needed for world > 1), or - single rank - any iterable of (images (B,16,3,64,64), tile_ids) batches
+    like the reference's DataLoader (scannet.py:147-155)."""
     from wsi_segmentation_pipeline_amd import bags as B
     class_probs = args.class_probs if class_probs is None else class_probs
     dev = _device_of(model)
     was_training = model.training
     model.eval()
-    data = iterator.dataset
-    R = len(data)
-    shards = B.shard_bags(np.full(R, 16.0), world)
+    data = getattr(iterator, 'dataset', None)
+    if world > 1 and (data is None or not hasattr(iterator, 'shard')):
+        raise ValueError('predict_regions over several ranks needs a shardable iterator (utils.dataset_hr.DeviceBagIterator)')
+    R = len(data) if data is not None else None
+    shards = B.shard_bags(np.full(R, 16.0), world) if world > 1 else None
     mine = iterator.shard(shards[rank]) if world > 1 else iterator
+    seen_ids = []                                             # plain iterables: the tile ids come with the batches
     with torch.no_grad():
         parts = []
         eng = model.hip_engine(dev) if world > 1 and hasattr(model, 'hip_engine') else None
         probed = not hasattr(eng, 'probe_f32')                # precision='auto' over several ranks: ONE mode for every rank
-        for images, _ in mine:
+        for images, tile_ids in mine:
+            if data is None:
+                seen_ids.extend(int(t) for t in tile_ids)
             images = images.to(dev)
             if not probed:
                 eng.reset()
@@ -291,11 +298,14 @@ def predict_regions(model, iterator, metadata, label_shape, class_probs=None, ra
         num_classes = len(class_probs)
         local = torch.cat(parts) if parts else torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
         ens = B.gather_rows(local, shards, rank, world) if world > 1 else local
+        if R is None:
+            R = len(seen_ids)
         if R:
             # (R,C) logits as a (C,R,1) "map": softmax over classes / threshold / argmax in one HIP kernel
             as_map = ens.t().to(torch.float64).contiguous().view(ens.shape[1], -1, 1)
             cls = E.softmax_threshold_argmax(as_map, class_probs, want_probs=False)[0].view(-1)
-            index_lists = [metadata[int(r['tile_id'])]['foreground_indices'] for r in data.datalist]
+            ids = [int(r['tile_id']) for r in data.datalist] if data is not None else seen_ids
+            index_lists = [metadata[t]['foreground_indices'] for t in ids]
             pred_mask = B.paint_regions(tuple(label_shape), index_lists, cls, dev).cpu().numpy()
         else:
             pred_mask = np.zeros(label_shape, dtype=np.int64)
