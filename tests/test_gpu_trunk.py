@@ -248,7 +248,9 @@ def test_ab_switches_agree(dev, sd):
         eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']))
         base = eng.forward_f32(x, logits=True)[1].clone()
         try:
-            for mode in (3, 1 + 8, 1 + 16, 1 + 32, 1 + 128, 1 + 256, 1 + 512, 3 + 32 + 128 + 256):
+            # (+2048: the strided blocks' downsample as its own tensor + residual instead of folded into the second conv; +4096:
+            #  layer-1 kernel without paired-tile addressing - that one must not change a bit)
+            for mode in (3, 1 + 8, 1 + 16, 1 + 32, 1 + 128, 1 + 256, 1 + 512, 3 + 32 + 128 + 256, 1 + 2048, 1 + 2048 + 4096):
                 native.check(lib.wsi_conv_set_mode(mode), 'conv mode')
                 alt = eng.forward_f32(x, logits=True)[1].clone()
                 err = float((alt - base).abs().max())
@@ -303,3 +305,27 @@ def test_trunk_set_chunks_equals_unchunked(dev, sd, planes):
     finally:
         lib.wsi_trunk_set_chunks(0, 0)
     assert lib.wsi_trunk_set_chunks(2, 3) != 0                    # layer1 chunk must be a multiple of the stem chunk
+
+
+def test_paired_tile_addressing_is_bit_identical(dev, sd):
+    """conv3x3s1_slab3_kernel<.., PAIR> (odd pixel tiles read at the even tile's LDS addresses + 4096 on 64-wide maps) against
+    the same kernel with every address computed: identical bits on 256x256 tiles (layer 1 is the only 64-wide stage), with and
+    without the residual; and 64x64 tiles (16-wide layer 1: PAIR not applicable) still run."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    g = torch.Generator(device=dev).manual_seed(9)
+    slide = torch.randint(0, 256, (256 * 2, 256 * 3, 3), dtype=torch.uint8, device=dev, generator=g)
+    xy = torch.tensor([[256 * (i % 3), 256 * (i // 3)] for i in range(6)], dtype=torch.int32, device=dev)
+    eng = TrunkEngine(sd, dev, planes=3, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=6)
+    base = [t.clone() for t in eng.forward_tiles(slide, xy, 256, 256, feat=True, logits=True, fmap=True)]
+    try:
+        native.check(lib.wsi_conv_set_mode(1 + 4096), 'conv mode')
+        alt = eng.forward_tiles(slide, xy, 256, 256, feat=True, logits=True, fmap=True)
+        for a, b in zip(alt, base):
+            assert torch.equal(a, b)
+    finally:
+        lib.wsi_conv_set_mode(1)
+    small = torch.randint(0, 256, (64, 64 * 5, 3), dtype=torch.uint8, device=dev, generator=g)
+    xy5 = torch.tensor([[64 * i, 0] for i in range(5)], dtype=torch.int32, device=dev)
+    assert bool(torch.isfinite(eng.forward_tiles(small, xy5, 64, 64, logits=True)[1]).all())
