@@ -298,7 +298,7 @@ def run_rank(args):
         # Dominant kernel = the stride-1 3x3 conv of layers 2-4 (9 launches per batch); algorithmic FLOPs = 2*M*N*K over
         # real output pixels (302 MFLOP per conv and 256x256 patch); split passes are not counted
         roofline = {'kernel': 'stride-1 3x3 convs of layers 2-4, 9 launches per batch: ' + {3: 'conv3x3s1_wide_kernel', 2: 'conv3x3s1_pp_kernel (layers 3-4) + conv3x3s1_slab3_kernel (layer 2)',
-                                                                                             1: 'conv3x3s1_pp_kernel (layers 3-4) + conv3x3s1_slab3_kernel (layer 2)'}[planes],
+                                                                                             1: 'conv3x3s1_wide_kernel (layers 2-3) + conv3x3s1_pp_kernel (layer 4)'}[planes],
                     'bound': 'mfma', 'achieved': round(k['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(k['tflops'] / PEAK_BF16_TFLOPS, 4),
                     'traffic': pmc_bytes(('conv3x3s1_wide', 'conv3x3s1_pp'), eff_batch),

@@ -1070,14 +1070,15 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     if (a.gi.W <= 4 && a.go.C % 128 == 0 && planes == 3) return 30;
     // r03 (fp6 line format, residual through the matrix pipe): in mx the 4-wave wide kernel - two workgroups per CU, so one
     // workgroup's tail runs beside the other's main loop - ties the ping-pong kernel without a residual and beats it by 2-3 %
-    // with one (profiles/r03_tune_conv_mx.log); the ping-pong kernel stays the default of the single-pass bf16 mode.
-    // (256-multiple outputs, layers 3-4; +4...7 % over slab3 there; it needs two slabs in LDS: maps wider than 33 fall back)
-    if (!fallback && planes == 1 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 70;
+    // with one (profiles/r03_tune_conv_mx.log).  Single-pass bf16 mode:
+    // (r03 tune of that mode, n = 2000, with / without residual: wide 0.60 / 0.70 (layer 2), 0.50 / 0.56, 0.47 / 0.50 ms against
+    // slab3 0.62 / 0.74 and ping-pong 0.52 / 0.59, 0.47 / 0.50: the wide kernel everywhere except 8x8 maps, where the two tie)
+    if (!fallback && planes == 1 && a.go.C % 256 == 0 && a.gi.W <= 8 && g_wide_min_c <= 256) return 70;
     // parity mode (r02 tune, n = 2000): the ping-pong kernel in its 256 px x 128 couts shape on layers 3-4 (1.48 / 1.38 vs 1.55 / 1.43 ms
     // for the wide kernel), slab3 on layer 2 (1.69 vs 1.78 ms)
     if (!fallback && planes == 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 83;
     if (planes == 2 && a.go.C == 128 && a.gi.W > 8 && g_wide_min_c <= 128) return 30;
-    if (planes >= 2 && a.go.C % 128 == 0 && a.go.C >= g_wide_min_c) return 60;
+    if (a.go.C % 128 == 0 && a.go.C >= g_wide_min_c && !(planes == 1 && a.gi.W > 33)) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
     if (a.go.C % 128 != 0 && planes == 3 && !fallback) return 38;         // r03 tune, layer 1: 1.416 / 1.619 ms vs 1.435 / 1.666 (cfg 31), n = 2000
     return a.go.C % 128 == 0 ? 30 : 31;
