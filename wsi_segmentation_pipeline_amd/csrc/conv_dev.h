@@ -230,6 +230,7 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
                                                     int ntile0, int lane, char* scratch, int slab0) {
     constexpr int T = NT * MT;
     static_assert(MT % NBUF == 0 || NBUF % MT == 0, "a batch is part of one channel tile or whole channel tiles");
+    static_assert(NBUF <= T && T % NBUF == 0, "whole batches");
     if (!a.resid) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile0 + nt, lane);

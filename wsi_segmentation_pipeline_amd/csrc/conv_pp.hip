@@ -238,7 +238,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3s1_pp_kernel(ConvArgs a, int xb
 #endif
     if (grp == 0) PP_BARRIER();                               // group A's matching extra barrier
     if constexpr (PLANES == 3) {                              // weight stages and slabs are dead: residual staging, NBUF tiles per wave
-        conv_tail_mx<NT, MT, (RESID_NBUF % MT == 0 ? RESID_NBUF : MT)>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096), slab0);
+        constexpr int NBUF = RESID_NBUF % MT ? MT : (RESID_NBUF < NT * MT ? RESID_NBUF : NT * MT);
+        conv_tail_mx<NT, MT, NBUF>(a, acc, qs, valid, nb * NTILES + wn * NT, lane, smem + wave * (RESID_NBUF * 4096), slab0);
     } else {
         char* scratch = nullptr;
         if (PLANES == 2 && a.resid && !(a.flags & CONV_RESID_DIRECT)) scratch = xl + wave * 8192;   // slabs are dead: residual staging
