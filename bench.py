@@ -253,7 +253,11 @@ def run_rank(args):
     prof_on = not args.no_prof
     per_rank_units = (units_per_step + world - 1) // world
     nb = max(1, -(-per_rank_units // (args.batch * (16 if args.workload == 'cfg4' else 1))))
-    launches_per_step = (24 if not args.chunks else 200) * nb
+    launches_per_step = 24 * nb
+    if args.chunks:                                         # sub-batched stem / layer 1: one stem launch per stem chunk, four convs per layer-1 chunk
+        cs_, c1_ = (int(v) for v in args.chunks.split(','))
+        per = min(args.batch, per_rank_units)
+        launches_per_step = nb * (16 + (-(-per // cs_) if cs_ else 1) + 4 * (-(-per // c1_) if c1_ else 1) + (-(-per // c1_) if c1_ and cs_ else 0))
     if prof_on and launches_per_step * args.steps <= 16384:
         native.check(lib.wsi_prof_begin(launches_per_step * args.steps), 'wsi_prof_begin')
     else:

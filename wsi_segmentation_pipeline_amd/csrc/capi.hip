@@ -786,6 +786,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     // byte offset of image n0 inside a PF buffer of stage s
     const size_t bpc = planes == 1 ? PFmt<1>::BPC : PFmt<2>::BPC;     // bytes per channel: 2 (speed) or 4 (parity, mx)
     auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * bpc; };
+    // ... and inside one phase image of stage 0's phase-split output (a PF tensor of stage 1's map size, 64 channels)
+    auto split_off = [&](int n0) { return (size_t)n0 * (p.sh[1] + 1) * (p.sw[1] + 1) * p.sc[0] * bpc; };
 
     // ---- stem + maxpool + layer1 run in sub-batches so that the 4 MB/patch fp32 stem scratch and
     //      the 1 MB/patch layer-1 tensors stay resident in the 256 MiB Infinity Cache; the deeper
@@ -796,7 +798,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     // stage s writes its output phase-split when the next stage's entry can read it with the wide stride-2 kernel:
     // full runs only (taps unpack ordinary PF), split precision, next output maps <= 33 wide, whole-batch stages
     auto can_split = [&](int s) { return allow_split && g_s2_split && g_s2_slab && stop_after >= 8 && planes >= 2 && s < 3 && p.sw[s + 1] <= 33; };
-    const bool split0 = can_split(0) && c1 >= n;
+    const bool split0 = can_split(0);                  // (a layer-1 sub-batch writes its images' slice of each phase image)
     int l1_out = 0;                                    // buffer index holding layer1's output
     for (int n1 = 0; n1 < n; n1 += c1) {
         const int nn1 = n - n1 < c1 ? n - n1 : c1;
@@ -820,7 +822,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
                                                                      H1, W1, 64, 64, 1, 1, planes, st));
             if (b == 1 && split0) {                    // layer1's output feeds only the stride-2 entry of layer2
-                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, ws + p.buf[0][3], x, wt->conv_w[3], wt->conv_b[3], nn1, H1, W1, 64,
+                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, ws + p.buf[0][3] + split_off(n1), x, wt->conv_w[3], wt->conv_b[3], nn1, H1, W1, 64,
                                                                   64, 1, 3, 1, planes, st, -1, 1, pf_alloc_pixels(cap, H1 / 2, W1 / 2)));
             } else {
                 PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
