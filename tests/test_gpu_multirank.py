@@ -162,8 +162,8 @@ def _seg_worker(rank, world, port, q, out_dir):
 
 
 def test_two_rank_seg_mode_equals_single_rank(tmp_path):
-    """predict_tumorbed(mode='seg') with the tile list cut over two ranks and ONE all-reduce of the float64 maps (SURVEY.md 8e,
-    seg mode) == the single-rank classes and heat map, byte for byte, on every rank."""
+    """predict_tumorbed(mode='seg') with the tile list cut over two ranks, the band gather of the float64 maps to rank 0 and the
+    broadcast of the u8 maps (seg mode) == the single-rank classes and heat map, byte for byte, on every rank."""
     ref = _seg(0, 1, str(tmp_path))
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

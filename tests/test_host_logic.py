@@ -301,6 +301,39 @@ def test_allreduce_map_gloo_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def test_tile_bands_cover_a_raster_share_disjointly():
+    """slide.tile_bands on contiguous raster shares of the reference grid (dataset.py:143-166: interior rows, then the edge column,
+    then the bottom row) at stride < tile: the rectangles are disjoint, contain every pixel the share's tiles touch, and the eight
+    shares together cost about one map (plus the overlap rows) - not world x the map, as the r02 all-reduce did."""
+    H = W = 500
+    ph, sh = 32, 24
+    ys, xs = list(range(1, H - 1 - ph, sh)), list(range(1, W - 1 - ph, sh))
+    tiles = [(x, y) for y in ys for x in xs] + [(W - 1 - ph, y) for y in ys] + [(x, H - 1 - ph) for x in xs]
+    tiles = np.asarray(tiles, np.int64)
+    total_px = 0
+    for world in (8, 3, 1):
+        sent = 0
+        for rank in range(world):
+            lo, hi = S.shard_range(len(tiles), rank, world)
+            rects = S.tile_bands(tiles[lo:hi], ph, ph, (H, W))
+            cover = np.zeros((H, W), np.int32)
+            for y0, y1, x0, x1 in rects.tolist():
+                cover[y0:y1, x0:x1] += 1
+            assert cover.max() <= 1                                             # disjoint
+            touched = np.zeros((H, W), bool)
+            for x, y in tiles[lo:hi].tolist():
+                touched[y:y + ph, x:x + ph] = True
+            assert bool((cover[touched] == 1).all())                            # complete
+            assert len(rects) <= 8
+            sent += int(cover.sum())
+        total_px = max(total_px, sent)
+        assert sent <= 1.45 * H * W                                             # overlap rows between shares + edge column / bottom row hulls
+    assert len(S.tile_bands(np.zeros((0, 2), np.int64), ph, ph, (H, W))) == 0   # a rank without tiles sends nothing
+    # tiles hanging over the map edge are clipped
+    r = S.tile_bands(np.asarray([[490, 490]]), ph, ph, (H, W))
+    assert r.tolist() == [[490, 500, 490, 500]]
+
+
 # ------------------------------------------------------------------------------ every collective at world 8 and 3, uneven and empty shards
 def _all_collectives_worker(rank, world, port, total, q):
     """One process of `world`: tile-logit gather, bag-row gather, map all-reduce, span / probe-error reductions - with `total`
@@ -329,7 +362,15 @@ def _all_collectives_worker(rank, world, port, total, q):
         ref[:, y:y + 8, x:x + 8] += tiles[t].double()
         if lo <= t < hi:
             pred[:, y:y + 8, x:x + 8] += tiles[t].double()
+    part = pred.clone()                                                              # (allreduce_map sums in place)
     ok['map'] = bool(torch.equal(S.allreduce_map(pred), ref))
+    # (3b) slide.gather_map_bands: the same sum as a direct band gather to rank 0 (what predict_tumorbed(mode='seg') uses);
+    #      the other ranks keep their partial maps; the u8 maps then travel by broadcast_from
+    mine_xy = xy[lo:hi].numpy()
+    got = S.gather_map_bands(part.clone(), mine_xy, 8, 8, rank, world, dst=0)
+    ok['bands'] = bool(torch.equal(got, ref)) if rank == 0 else bool(torch.equal(got, part))
+    u8 = (ref[0] > 0).to(torch.uint8) if rank == 0 else torch.empty(32, 32, dtype=torch.uint8)
+    ok['bcast'] = bool(torch.equal(S.broadcast_from(u8, 0), (ref[0] > 0).to(torch.uint8)))
     # (4) the reductions beside it: exponent span (None on a rank without tiles) and the precision probe's maximum
     span = torch.tensor([120 + rank, 130 - rank], dtype=torch.int32) if hi > lo else None
     owners = [r for r in range(world) if S.shard_range(total, r, world)[1] > S.shard_range(total, r, world)[0]]

@@ -116,13 +116,15 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                 pred = torch.zeros((args.num_classes,) + tuple(map_hw), dtype=torch.float64, device=dev)
                 dy, dx = int(m * ds.params.ph), int(m * ds.params.pw)
                 # world > 1 (seg mode): every rank runs a contiguous share of the raster-order tile list into its
-                # own map, then ONE all-reduce (sum) of the float64 maps - exact, hence identical to the single-rank map, inside
-                # the exponent-span bound of the stitch
+                # own map and sends the band its tiles touch to rank 0 (slide.gather_map_bands: a direct gather, no all-reduce);
+                # rank 0 sums the bands - exact, hence identical to the single-rank map, inside the exponent-span bound of the
+                # stitch - thresholds, and broadcasts the two u8 maps
                 my_it = it
                 if world > 1:
                     lo, hi = S.shard_range(len(ds), rank, world)
                     my_it = it.shard(lo, hi)
                 span_lo, span_hi = None, None                 # exponent range of every addend: the exactness guard of the float64 sums
+                my_txy = []
                 for batch_x, batch_y, batch_image in my_it:
                     pred_src = model.decoder(model.encoder(batch_image.to(dev)))
                     if args.scan_resize != 1:
@@ -131,17 +133,23 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                         raise ValueError("mode='seg': the decoder output %s does not match the stitch footprint (%d, %d) = int(m * tile); "
                                          "scan at the map's level or set scan_resize (utils/eval.py:202-215)" % (tuple(pred_src.shape[2:]), dy, dx))
                     xy = np.stack((batch_x.numpy(), batch_y.numpy()), 1)
-                    E.stitch_add_dense(pred, pred_src, torch.from_numpy(S.map_coords(xy, m)))
+                    txy = S.map_coords(xy, m)
+                    my_txy.append(np.asarray(txy))
+                    E.stitch_add_dense(pred, pred_src, torch.from_numpy(txy))
                     sp = E.exponent_span(pred_src)
                     span_lo = sp[0:1] if span_lo is None else torch.minimum(span_lo, sp[0:1])
                     span_hi = sp[1:2] if span_hi is None else torch.maximum(span_hi, sp[1:2])
                 span = torch.cat((span_lo, span_hi)) if span_lo is not None else None
                 if world > 1:
-                    # (a deviation from SURVEY.md 8e, which sketches a band gather: tiles of a raster-order share overlap their
-                    # neighbours' bands when stride < tile, so the bands need a sum anyway; one all-reduce is that sum)
-                    pred = S.allreduce_map(pred)
+                    txy_all = np.concatenate(my_txy) if my_txy else np.zeros((0, 2), np.int64)
+                    pred = S.gather_map_bands(pred, txy_all, dy, dx, rank, world, dst=0)
                     span = S.allreduce_span(span, dev)
-                classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'seg', want_probs=False)
+                if world == 1 or rank == 0:
+                    classes, _, heat = E.softmax_threshold_argmax(pred, args.class_probs, mask, 'seg', want_probs=False)
+                else:
+                    classes, heat = (torch.empty(tuple(map_hw), dtype=torch.uint8, device=dev) for _ in range(2))
+                if world > 1:
+                    classes, heat = S.broadcast_from(classes, 0), S.broadcast_from(heat, 0)
                 r = {'logits': None, 'pred': pred, 'classes': classes, 'heatmap': heat, 'exponent_span': span}
             stitch_exact = None
             if r.get('exponent_span') is not None:             # the float64 stitch is exact (order- and rank-independent) inside this

@@ -222,6 +222,92 @@ def allreduce_map(pred):
     return host.to(pred.device)
 
 
+def tile_bands(txy, dy, dx, hw):
+    """Disjoint rectangles (y0, y1, x0, x1) of a (H, W) map covering everything a set of tiles touches: `txy` (T, 2) map
+    coordinates (x, y) of footprints dy x dx.  Per map row the touched column extent is the hull of the tiles on that row; runs
+    of rows with the same extent form one rectangle.  A contiguous raster share of a tile grid gives at most a handful (first
+    partial tile row, full rows, last partial row, the edge column, the bottom row)."""
+    H, W = int(hw[0]), int(hw[1])
+    txy = np.asarray(txy, np.int64).reshape(-1, 2)
+    lo, hi = np.full(H, W, np.int64), np.zeros(H, np.int64)
+    for y in np.unique(txy[:, 1]) if len(txy) else ():
+        xs = txy[txy[:, 1] == y, 0]
+        a, b = max(int(y), 0), min(int(y) + dy, H)
+        lo[a:b] = np.minimum(lo[a:b], max(int(xs.min()), 0))
+        hi[a:b] = np.maximum(hi[a:b], min(int(xs.max()) + dx, W))
+    rects, y = [], 0
+    while y < H:
+        if hi[y] <= lo[y]:
+            y += 1
+            continue
+        e = y + 1
+        while e < H and lo[e] == lo[y] and hi[e] == hi[y]:
+            e += 1
+        rects.append((y, e, int(lo[y]), int(hi[y])))
+        y = e
+    return np.asarray(rects, np.int64).reshape(-1, 4)
+
+
+def gather_map_bands(pred, txy, dy, dx, rank, world, dst=0):
+    """Dense 'seg' mode exchange ("gather band shards of the map ... no all-reduce on this path"): every rank
+    stitched a contiguous raster share of the tiles into its own float64 (C, H, W) map; each sends ONLY the rectangles its tiles
+    touch (`tile_bands`), packed into one buffer, straight to `dst`, which posts all its receives at once (7 concurrent xGMI
+    links under RCCL) and adds them into its map.  Neighbouring shares overlap by a few rows when stride < tile, hence a sum,
+    not a copy - exact in float64 inside the stitch's exponent-span bound, so `dst` ends with the single-rank map bit for bit.
+    Bytes: each rank sends its band (~1/world of the map, 200 MB / 8 at 4 x 2500^2) once; the r02 all-reduce moved the whole map
+    through every rank twice.  Returns `pred`: complete on `dst`, this rank's partial map elsewhere."""
+    import torch.distributed as dist
+    if world == 1:
+        return pred
+    C = pred.shape[0]
+    rects = tile_bands(txy, dy, dx, pred.shape[1:])
+    via_host = dist.get_backend() != 'nccl' and pred.is_cuda
+    on = 'cpu' if (via_host or not pred.is_cuda) else pred.device
+    # rectangle tables of every rank (a few dozen bytes): count first, then the padded tables
+    cnt = torch.tensor([len(rects)], dtype=torch.int64, device=on)
+    cnts = torch.empty(world, dtype=torch.int64, device=on)
+    dist.all_gather_into_tensor(cnts, cnt)
+    cnts = cnts.cpu().tolist()
+    kmax = max(max(cnts), 1)
+    tab = torch.zeros((kmax, 4), dtype=torch.int64, device=on)
+    if len(rects):
+        tab[:len(rects)] = torch.from_numpy(rects).to(on)
+    tabs = torch.empty((world * kmax, 4), dtype=torch.int64, device=on)
+    dist.all_gather_into_tensor(tabs, tab)
+    tabs = tabs.view(world, kmax, 4).cpu().numpy()
+    numel = lambda r: int(sum(C * (t[1] - t[0]) * (t[3] - t[2]) for t in tabs[r, :cnts[r]]))
+    if rank != dst:
+        if len(rects):
+            buf = torch.cat([pred[:, y0:y1, x0:x1].reshape(-1) for y0, y1, x0, x1 in rects.tolist()])
+            buf = buf.cpu() if via_host else buf
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst)]):
+                q.wait()
+        return pred
+    srcs = [r for r in range(world) if r != dst and cnts[r]]
+    bufs = {r: torch.empty(numel(r), dtype=pred.dtype, device=on) for r in srcs}
+    if srcs:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, bufs[r], r) for r in srcs]):
+            q.wait()
+    for r in srcs:
+        b, off = bufs[r].to(pred.device), 0
+        for y0, y1, x0, x1 in tabs[r, :cnts[r]].tolist():
+            n = C * (y1 - y0) * (x1 - x0)
+            pred[:, y0:y1, x0:x1] += b[off:off + n].view(C, y1 - y0, x1 - x0)
+            off += n
+    return pred
+
+
+def broadcast_from(t, src=0):
+    """Broadcast a tensor (here: the u8 class / heat maps, 6 MB each at 2500^2) from `src`; gloo with device tensors goes via host."""
+    import torch.distributed as dist
+    if dist.get_backend() == 'nccl' or not t.is_cuda:
+        dist.broadcast(t, src)
+        return t
+    host = t.cpu()
+    dist.broadcast(host, src)
+    return host.to(t.device)
+
+
 # ------------------------------------------------------------------------------ rank-resident slide regions
 class SyntheticRows:
     """Position-deterministic i.i.d. uniform u8 RGB slide level: rows are generated on the
