@@ -425,26 +425,40 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
         }
         }
         // bias + ReLU + validity mask, vertical max with the carried row, keep row 2py+1 as the next carry
-        const bool r0_ok = (2 * py) >= 0 && (2 * py) < Hc, r1_ok = (2 * py + 1) >= 0 && (2 * py + 1) < Hc;
         float v[16];
+        if constexpr (U8X) {
+            // Integer path: the carried row and the vertical max live in the RAW domain (the exact digit recombination, before the
+            // channel's scale and shift).  scale > 0 (wsi_prepack_stem_u8), so x -> max(fma(x, scale, shift), 0) is monotone,
+            // rounding included, and commutes with the maximum: one FMA + ReLU per pooled value instead of one per conv value,
+            // bit-identical.  Conv rows 2py, 2py+1 are inside the map for every py >= 0; above the image (py = -1, the carry-only
+            // step of the first segment) the carry is the pool's padding, -FLT_MAX here.
+            auto raw = [&](int mt, int r) {                             // exact recombination of the digit planes
+                float c = (float)(DIG >= 2 ? aq[mt][DIG >= 2 ? 1 : 0][r] * 256 + aq[mt][0][r] : aq[mt][0][r]);
+                if constexpr (DIG == 3) c = __builtin_fmaf((float)aq[mt][DIG - 1][r], 65536.0f, c);
+                return c;
+            };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float c0, c1, sh;
-            if constexpr (U8X) {                                        // exact recombination of the digit planes, then the channel's scale
-                const int l0 = DIG >= 2 ? aq[0][DIG >= 2 ? 1 : 0][r] * 256 + aq[0][0][r] : aq[0][0][r];
-                const int l1 = DIG >= 2 ? aq[1][DIG >= 2 ? 1 : 0][r] * 256 + aq[1][0][r] : aq[1][0][r];
-                c0 = (float)l0; c1 = (float)l1;
-                if constexpr (DIG == 3) { c0 = __builtin_fmaf((float)aq[0][DIG - 1][r], 65536.0f, c0); c1 = __builtin_fmaf((float)aq[1][DIG - 1][r], 65536.0f, c1); }
+            for (int r = 0; r < 16; ++r) {
+                const float c0 = raw(0, r), c1 = raw(1, r);
+                const float m = fmaxf(fmaxf(carry[r], c0), c1);
+                carry[r] = c1;
                 const int ch = wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                const float qs = sb_lds[ch];
-                sh = sb_lds[64 + ch];
-                c0 = __builtin_fmaf(c0, qs, sh); c1 = __builtin_fmaf(c1, qs, sh);       // explicit FMAs (the build runs with -ffp-contract=off)
-                sh = 0.f;
-            } else { c0 = acc[0][r]; c1 = acc[1][r]; sh = bias[r]; }
-            const float a0 = (col_ok && r0_ok) ? fmaxf(c0 + sh, 0.f) : 0.f;
-            const float a1 = (col_ok && r1_ok) ? fmaxf(c1 + sh, 0.f) : 0.f;
-            v[r] = fmaxf(fmaxf(carry[r], a0), a1);
-            carry[r] = a1;
+                const float t = fmaxf(__builtin_fmaf(m, sb_lds[ch], sb_lds[64 + ch]), 0.f);   // explicit FMA (the build runs with -ffp-contract=off)
+                v[r] = col_ok ? t : 0.f;                                // columns outside the map are the pool's padding
+            }
+            if (py < 0) {                                               // (uniform; first step of the first segment only)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) carry[r] = -3.4028234e38f;
+            }
+        } else {
+            const bool r0_ok = (2 * py) >= 0 && (2 * py) < Hc, r1_ok = (2 * py + 1) >= 0 && (2 * py + 1) < Hc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a0 = (col_ok && r0_ok) ? fmaxf(acc[0][r] + bias[r], 0.f) : 0.f;
+                const float a1 = (col_ok && r1_ok) ? fmaxf(acc[1][r] + bias[r], 0.f) : 0.f;
+                v[r] = fmaxf(fmaxf(carry[r], a0), a1);
+                carry[r] = a1;
+            }
         }
         if (py >= py0) {
             // horizontal 3-max: pooled column px0+j sits on odd lane 2j+1 of each 32-lane half
