@@ -323,6 +323,25 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
 }
 
 
+// Study builds: where a wave of the wide kernel spends its cycles (tools/wide_stamps.py).  s_memtime stamps around the
+// phases, summed over the waves of a launch: [0] waves, [1] lifetime, [2] tile set-up, [3] first line's slab + weights
+// (prologue), [4] later lines' slab waits, [5] tap-end waits (weight DMA + barrier), [6] tail (extra K segment, residual,
+// encode, stores).  The multiply phases are the rest.
+#ifdef WSI_STUDY
+__device__ unsigned long long g_wide_stamps[8];
+#define WSTAMP(...) __VA_ARGS__
+extern "C" int wsi_study_wide_stamps(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wide_stamps), sizeof(g_wide_stamps)) != hipSuccess) return WSI_EFAULT;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamps), z, sizeof(z)) != hipSuccess) return WSI_EFAULT;
+    }
+    return WSI_OK;
+}
+#else
+#define WSTAMP(...)
+#endif
+
 // --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
 // 128 accumulator registers), so a pixel-fragment set read from LDS feeds SIX MFMAs instead of three and the
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     char* const wl = smem;                                    // 2 weight buffers of NTILES x 4 KB
     char* const xl = smem + 2 * WB;                           // pixel slab
     const int tid = threadIdx.x, lane = tid & 63;
+    WSTAMP(const unsigned long long st_begin = __builtin_readcyclecounter(); unsigned long long st_pro = 0, st_line = 0, st_tap = 0, st_a = 0;)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
@@ -421,13 +441,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     };
 
     int kpar = 0;                                             // weight buffer of the current tap
+    WSTAMP(const unsigned long long st_setup = __builtin_readcyclecounter();)
     for (int c = 0; c < NC; ++c) {
+        WSTAMP(st_a = __builtin_readcyclecounter();)
         if (c) __syncthreads();                               // slab and weight buffers are free again
         for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
             dma16_buf(xrs, xl + (size_t)i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
         wdma(c, 0, wl + kpar * WB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a;)
         int Pc = P;
         asm volatile("" : "+s"(Pc));
         bf16x8 xf[2][4], wf[NT][4];
@@ -455,12 +478,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
                 }
             }
             if (t < 8) {
+                WSTAMP(st_a = __builtin_readcyclecounter();)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tap's weights have landed ...
                 __syncthreads();                                    // ... for everyone, and this tap's buffer is free
+                WSTAMP(st_tap += __builtin_readcyclecounter() - st_a;)
             }
             kpar ^= 1;
         }
     }
+    WSTAMP(const unsigned long long st_loop_end = __builtin_readcyclecounter();)
     if constexpr (PLANES == 3) {
         if (a.in2) {
             // Extra K segment (common.h ConvArgs.in2): the strided block's 1x1 downsample of the block input, one centre tap per
@@ -520,6 +546,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) conv_epilogue_q<MT, PLANES>(a, acc[nt], qs, valid, nb * NTILES + wn * NT + nt, lane, scratch);
     }
+#ifdef WSI_STUDY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the stores count as tail)
+    if (lane == 0) {
+        const unsigned long long st_end = __builtin_readcyclecounter();
+        atomicAdd(&g_wide_stamps[0], 1ull);
+        atomicAdd(&g_wide_stamps[1], st_end - st_begin);
+        atomicAdd(&g_wide_stamps[2], st_setup - st_begin);
+        atomicAdd(&g_wide_stamps[3], st_pro);
+        atomicAdd(&g_wide_stamps[4], st_line);
+        atomicAdd(&g_wide_stamps[5], st_tap);
+        atomicAdd(&g_wide_stamps[6], st_end - st_loop_end);
+    }
+#endif
 }
 
 
