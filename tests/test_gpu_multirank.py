@@ -73,6 +73,56 @@ def test_two_rank_pipeline_equals_single_rank(resident):
             assert np.array_equal(got[rank][k], ref[k].numpy()), (rank, k)
 
 
+def _few_tiles(rank, world, ntiles):
+    """Fewer tiles than ranks (rank 1 owns nothing) or no foreground tile at all, precision='auto' (whose probe is a collective)."""
+    from wsi_segmentation_pipeline_amd import slide as S, synthetic as W
+    from wsi_segmentation_pipeline_amd.engine import AutoTrunkEngine
+    dev = torch.device('cuda:0')
+    sd = W.make_resnet18_state_dict(11, with_fc=False)
+    cls = W.make_head_state_dict(22, 'classifier')
+    src = S.SyntheticRows(790, 530, 5, dev, block=64)
+    tiles = S.tile_grid(790, 530, 64, 64, 48, 48)[37:37 + ntiles]
+    eng = AutoTrunkEngine(sd, dev, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=64)
+    out = S.infer_slide_cls(eng, src.full(), tiles, 64, 64, 0.25, (132, 197), 4, (0., 0., 0., 0.), None, rank, world)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
+    res['mode'] = out['precision']['mode']
+    return res
+
+
+def _few_worker(rank, world, port, q, ntiles):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    q.put((rank, _few_tiles(rank, world, ntiles)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ntiles', [1, 0])
+def test_two_ranks_with_fewer_tiles_than_ranks(ntiles):
+    """One tile over two ranks (rank 1's shard is empty: no trunk call, but it still joins the probe reduction and the gather)
+    and a slide without a single foreground tile (the reference drops such slides, dataset.py:198-201; here the map is all
+    zeros: softmax 1/C everywhere): both ranks return the single-rank result."""
+    ref = _few_tiles(0, 1, ntiles)
+    assert ref['logits'].shape == (ntiles, 4) and ref['heatmap'].shape == (132, 197)
+    if ntiles == 0:
+        assert not ref['pred'].any() and int(ref['heatmap'].max()) == int(255 * 0.25)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_few_worker, args=(r, 2, port, q, ntiles)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for rank in (0, 1):
+        assert got[rank]['mode'] == ref['mode']
+        for k in ('logits', 'pred', 'classes', 'heatmap'):
+            assert np.array_equal(got[rank][k], ref[k]), (rank, k)
+
+
 # ------------------------------------------------------------------------------ region bags over two ranks (cfg4)
 def _regions(rank, world):
     import myargs
