@@ -160,7 +160,8 @@ int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const ui
                       void* stream);
 /* Sub-batching of the early (large-map) stages so their tensors stay in the 256 MiB Infinity Cache:
  * stem+maxpool run `stem_chunk` images at a time, layer1 `layer1_chunk` (a multiple of stem_chunk);
- * 0 = whole batch (default; measured on MI355X: sub-batching gives no gain at batch 500).  Process-wide. */
+ * 0 = whole batch (default; measured on MI355X, r03: every chunk size from 32 to 768 is slower than the whole batch at
+ * 6 162 tiles - DESIGN.md section 4).  Results are bit-identical to the unchunked run for every setting.  Process-wide. */
 int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk);
 /* debug / parity taps: run the trunk up to stage `stop_after` (0 = stem+maxpool output, 1..8 =
  * layer1.0, layer1.1, ..., layer4.1) and unpack that tensor to f32 NCHW. */
