@@ -316,14 +316,18 @@ def run_rank(args):
         bpc = 2 if planes == 1 else 4
         tensor = eff_batch * 64 * 64 * 64 * bpc
         # algorithmic bytes per launch: unfused conv = input + output (+ residual on every second launch) = 2.5 tensors on
-        # average; fused BasicBlock = input + output (the residual is the input, the intermediate never leaves the CU)
-        alg = (2.0 if fusedk else 2.5) * tensor
+        # average; fused BasicBlock = input + output (the residual is the input, the intermediate never leaves the CU).
+        # r03, mx: stem output and layer-1 tensors are stored in 96-byte lines (3 of the 4 bytes per channel),
+        # except the last conv's output: (4 inputs + 3 outputs + 2 residuals) x 0.75 + 1 output = 7.75 tensors over 4 launches
+        lines96 = planes == MX and not (args.s2 >= 0 and args.s2 & 16384) and not fusedk
+        alg = (2.0 if fusedk else 7.75 / 4 if lines96 else 2.5) * tensor
         gbs = alg / (l1['avg_ms'] * 1e-3) / 1e9
         roofline_l1 = {'kernel': ('layer1_block_kernel (2 launches per batch: one fused 64-channel BasicBlock each)' if fusedk else
                                   'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)'), 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': pmc_bytes('layer1_block' if fusedk else 'conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
-                       'algorithmic_bytes_per_launch': round(alg), 'avg_launch_ms': round(l1['avg_ms'], 4), 'tflops': round(l1['tflops'], 2)}
+                       'algorithmic_bytes_per_launch': round(alg), 'line_bytes': 96 if lines96 else 128,
+                       'avg_launch_ms': round(l1['avg_ms'], 4), 'tflops': round(l1['tflops'], 2)}
 
     # the same dominant kernel in single-pass bf16 (the literal dtype of BASELINE configs[1]; logit error ~2e-2, outside the
     # contract, so never the headline): one profiled pass on rank 0, outside the timed region

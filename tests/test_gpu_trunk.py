@@ -326,3 +326,36 @@ def test_paired_tile_addressing_is_bit_identical(dev, sd):
     small = torch.randint(0, 256, (64, 64 * 5, 3), dtype=torch.uint8, device=dev, generator=g)
     xy5 = torch.tensor([[64 * i, 0] for i in range(5)], dtype=torch.int32, device=dev)
     assert bool(torch.isfinite(eng.forward_tiles(small, xy5, 64, 64, logits=True)[1]).all())
+
+
+def test_96_byte_layer1_lines_are_bit_identical(dev, sd):
+    """r03: a full mx trunk run keeps the stem output and the layer-1 tensors in 96-byte lines (no hi6 plane in memory; the
+    layer-1 kernel rebuilds it in LDS from the fp16 plane with one v_cvt_scalef32_pk32_fp6_f16 per line) - identical bits to the
+    128-byte route (wsi_conv_set_mode + 16384) for the u8 and the f32 input paths, on 256x256 tiles (64-wide layer 1, paired
+    tiles), 64x64 crops (16-wide) and 128x192 tiles; and a workspace that alternates between full runs (96-byte lines in the
+    stage-0 buffers) and tap runs (128-byte lines in the SAME buffers, whose pad bytes sit elsewhere) stays exact."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    g = torch.Generator(device=dev).manual_seed(19)
+    eng = TrunkEngine(sd, dev, planes=3, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=7)
+    for th, tw, n in ((256, 256, 7), (64, 64, 5), (128, 192, 3)):
+        slide = torch.randint(0, 256, (th * 2, tw * 4, 3), dtype=torch.uint8, device=dev, generator=g)
+        xy = torch.tensor([[tw * (i % 4), th * (i // 4)] for i in range(n)], dtype=torch.int32, device=dev)
+        x = torch.randn(n, 3, th, tw, device=dev, generator=g)
+
+        def run():
+            return ([t.clone() for t in eng.forward_tiles(slide, xy, th, tw, feat=True, logits=True, fmap=True)] +
+                    [t.clone() for t in eng.forward_f32(x, feat=True, logits=True, fmap=True)])
+        new = run()
+        tap1 = eng.forward_tiles(slide, xy, th, tw, logits=False, tap=1).clone()      # 128-byte lines in the buffers the full run left in 96
+        again = run()                                                              # ... and back
+        try:
+            native.check(lib.wsi_conv_set_mode(1 + 16384), 'conv mode')
+            old = run()
+            tap1_old = eng.forward_tiles(slide, xy, th, tw, logits=False, tap=1).clone()
+        finally:
+            lib.wsi_conv_set_mode(1)
+        for a, b, c in zip(new, old, again):
+            assert torch.equal(a, b) and torch.equal(a, c), (th, tw)
+        assert torch.equal(tap1, tap1_old)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--n', type=int, default=2000)
     ap.add_argument('--planes', type=int, default=3)
     ap.add_argument('--cfg', type=int, default=60)
+    ap.add_argument('--shape', type=str, default='', help='one C,H,W shape instead of the layer-2/3/4 ones (64,64,64 with --cfg 38: the layer-1 slab3 kernel)')
     args = ap.parse_args()
     lib = native.load()
     if not hasattr(lib, 'wsi_study_wide_stamps'):
@@ -30,7 +31,7 @@ def main():
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(0)
     print('%-26s %8s %9s | %6s %6s %6s %6s %6s %6s' % ('shape', 'ms', 'cyc/wave', 'setup', 'prolog', 'lines', 'taps', 'tail', 'mult'))
-    for (c, h, w) in SHAPES:
+    for (c, h, w) in ([tuple(int(v) for v in args.shape.split(','))] if args.shape else SHAPES):
         n = args.n
         x = torch.randn(n, c, h, w, generator=g).abs_()
         wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5

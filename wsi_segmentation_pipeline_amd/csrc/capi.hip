@@ -1,6 +1,8 @@
 // extern "C" surface of libwsi_hip.so (include/wsi_hip.h): argument checking, host-side weight
-// prepack, and the trunk launch sequence.  No allocation, no synchronisation, no exceptions.
+// prepack, and the trunk launch sequence.  No device allocation, no synchronisation, no exceptions.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 #include "../../include/wsi_hip.h"
 #include <math.h>
 #include <string.h>
@@ -9,7 +11,7 @@ int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);
 int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st);
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
 int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
-int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st);
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96 = 0);
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
                             float* logits, int planes, hipStream_t st);
 int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
@@ -325,11 +327,12 @@ int wsi_stem_set_mode(int fused, int rows_per_seg) {
     return WSI_OK;
 }
 
-int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
-                                     int slide_h, int slide_w, const int* tile_xy, const float* lut,
-                                     const void* stem_wpk, const float* stem_bias, const void* stem_wpk_u8,
-                                     const float* stem_bias_u8, const float* norm_mean_std, int n, int h, int w,
-                                     float* scratch, void* out_pf, int planes, void* stream) {
+// out96 (trunk, mode 3): the pooled map is written in 96-byte lines (common.h CONV_OUT96) for a layer-1 kernel that reads them
+static int stem_run(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
+                    int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                    const void* stem_wpk, const float* stem_bias, const void* stem_wpk_u8,
+                    const float* stem_bias_u8, const float* norm_mean_std, int n, int h, int w,
+                    float* scratch, void* out_pf, int planes, void* stream, int out96) {
     if (!stem_wpk || !stem_bias || !scratch || !out_pf || n <= 0 || h % 16 || w % 4) return WSI_EINVAL;
     if (!in_f32 && (!slide || !tile_xy || !lut)) return WSI_EINVAL;
     StemArgs a;
@@ -341,10 +344,20 @@ int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, 
     // integer stem for u8 slide input (the transform is inside the packed weights; norm_mean_std is kept in the signature
     // for ABI stability and as the caller's statement of which transform those weights carry)
     if (stem_wpk_u8 && stem_bias_u8 && norm_mean_std && !in_f32 && g_stem_u8x) { a.wpk_u8 = stem_wpk_u8; a.bias_u8 = stem_bias_u8; }
-    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream);
+    if (out96 && planes != 3) return WSI_EINVAL;
+    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream, out96);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
     return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
+}
+
+int wsi_stem_conv7x7_bn_relu_maxpool(const float* in_f32, const uint8_t* slide, long long slide_pitch_bytes,
+                                     int slide_h, int slide_w, const int* tile_xy, const float* lut,
+                                     const void* stem_wpk, const float* stem_bias, const void* stem_wpk_u8,
+                                     const float* stem_bias_u8, const float* norm_mean_std, int n, int h, int w,
+                                     float* scratch, void* out_pf, int planes, void* stream) {
+    return stem_run(in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, stem_wpk, stem_bias, stem_wpk_u8, stem_bias_u8,
+                    norm_mean_std, n, h, w, scratch, out_pf, planes, stream, 0);
 }
 
 static int g_s2_slab = 1;                             // stride-2 convs: phase-slab kernel (1) or per-tap gather kernel (0)
@@ -359,8 +372,12 @@ extern "C" int wsi_study_set_debug(void* dev_buf) { g_study_debug = dev_buf; ret
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
                        int cfg = -1, int split_out = 0, long long split_pixels = 0, const void* in2 = nullptr, int in2_c = 0,
-                       const void* wpk2 = nullptr, const float* bias2 = nullptr) {
+                       const void* wpk2 = nullptr, const float* bias2 = nullptr, int line_flags = 0) {
     if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
+    // 96-byte lines (CONV_IN96 / OUT96 / RESID96): mode 3, stride-1 3x3, 64 channels in and out (the slab3 kernel), no phase split
+    if (line_flags && (planes != 3 || stride != 1 || ksize != 3 || cin != 64 || cout != 64 || (split_out && (line_flags & CONV_OUT96)) ||
+                       (line_flags & ~(CONV_IN96 | CONV_OUT96 | CONV_RESID96)) || ((line_flags & CONV_RESID96) && !resid_pf)))
+        return WSI_EINVAL;
     if ((stride != 1 && stride != 2) || h_in % stride || w_in % stride) return WSI_EINVAL;
     ConvArgs a;
     a.in = in_pf; a.out = out_pf; a.resid = resid_pf; a.wpk = wpk; a.bias = bias;
@@ -381,6 +398,7 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
 #else
     if (relu & ~1) return WSI_EINVAL;
 #endif
+    a.flags |= line_flags;
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
     if (in2) {                                         // extra K segment (common.h ConvArgs.in2): mode 3, stride-1 3x3, wide kernel only
         if (planes != 3 || stride != 1 || ksize != 3 || resid_pf || !wpk2 || !bias2 || in2_c <= 0 || in2_c % 32 || cout % 128 || cfg >= 0) return WSI_EINVAL;
@@ -473,10 +491,12 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
 }
 
 extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_ranges, g_slab_pair;
+extern int g_l1_lines96;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
     g_ds_fold = (s2_slab & 2048) ? 0 : 1;
     g_slab_pair = (s2_slab & 4096) ? 0 : 1;
+    g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_xcd_ranges = (s2_slab & 256) ? 0 : (s2_slab & 512) ? 1 : 2;          // +256: off, +512: 64-channel layer only
     g_s2_ablate = (s2_slab & 64) ? 1 : 0;                 // bottleneck study only: stride-2 kernel without weight loads (wrong results)
     g_xcd_order = (s2_slab & 8) ? 1 : 0;
@@ -716,6 +736,22 @@ static inline void prof_close(hipStream_t st, int i) { if (i >= 0) (void)hipEven
 // ------------------------------------------------------------------------------------ trunk
 static int g_chunk_stem = 0, g_chunk_l1 = 0;   // sub-batch sizes (images); 0 = whole batch (measured r01: no gain)
 
+// Layer-1 tensors of a full mode-3 trunk run live in 96-byte lines (common.h CONV_IN96): the pad positions of a PF buffer sit at
+// other BYTES than in the 128-byte layout, and pads are only ever zero because nobody writes them - so a workspace remembers
+// which layout its three stage-0 buffers last held, and a run in the other layout zero-fills them first (taps and the U-Net
+// encoder keep the 128-byte layout; a workspace that only ever runs one kind of call never pays).  -1 = all zero (after
+// wsi_trunk_workspace_init), 0 = 128-byte lines, 1 = 96-byte lines; an unknown workspace counts as dirty.
+int g_l1_lines96 = 1;                           // A/B: wsi_conv_set_mode +16384 disables
+static std::mutex g_ws_mutex;
+static std::unordered_map<const void*, int> g_ws_layout;
+static int ws_layout_switch(const void* ws, int want) {      // returns 1 if the stage-0 buffers must be zero-filled first
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    auto it = g_ws_layout.find(ws);
+    const int have = it == g_ws_layout.end() ? -2 : it->second;
+    g_ws_layout[ws] = want;
+    return !(have == want || have == -1);
+}
+
 int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk) {
     if (stem_chunk < 0 || layer1_chunk < 0) return WSI_EINVAL;
     if (stem_chunk && layer1_chunk && layer1_chunk % stem_chunk) return WSI_EINVAL;
@@ -755,6 +791,10 @@ size_t wsi_trunk_workspace_bytes(int n, int h, int w, int planes) {
 int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, void* stream) {
     TrunkPlan p;
     if (!workspace || trunk_plan(n, h, w, planes, p)) return WSI_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mutex);
+        g_ws_layout[workspace] = -1;
+    }
     return hipMemsetAsync((char*)workspace + p.buf[0][0], 0, p.total - p.buf[0][0], (hipStream_t)stream) == hipSuccess
                ? WSI_OK
                : WSI_EFAULT;
@@ -783,12 +823,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
         prof_close(st, pi_);                                                                        \
         if (rc) return rc;                                                                          \
     } while (0)
-    // byte offset of image n0 inside a PF buffer of stage s
     const size_t bpc = planes == 1 ? PFmt<1>::BPC : PFmt<2>::BPC;     // bytes per channel: 2 (speed) or 4 (parity, mx)
-    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * bpc; };
-    // ... and inside one phase image of stage 0's phase-split output (a PF tensor of stage 1's map size, 64 channels)
-    auto split_off = [&](int n0) { return (size_t)n0 * (p.sh[1] + 1) * (p.sw[1] + 1) * p.sc[0] * bpc; };
-
     // ---- stem + maxpool + layer1 run in sub-batches so that the 4 MB/patch fp32 stem scratch and
     //      the 1 MB/patch layer-1 tensors stay resident in the 256 MiB Infinity Cache; the deeper
     //      (small-map) stages run on the whole batch to fill the chip.
@@ -799,17 +834,30 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     // full runs only (taps unpack ordinary PF), split precision, next output maps <= 33 wide, whole-batch stages
     auto can_split = [&](int s) { return allow_split && g_s2_split && g_s2_slab && stop_after >= 8 && planes >= 2 && s < 3 && p.sw[s + 1] <= 33; };
     const bool split0 = can_split(0);                  // (a layer-1 sub-batch writes its images' slice of each phase image)
+    // r03: a full mode-3 run keeps stem output and layer-1 tensors in 96-byte lines (layer 1 is HBM-bound: 25 % fewer bytes);
+    // the last layer-1 conv writes the ordinary (or phase-split) 128-byte form every other kernel reads
+    // (only with the phase-split hand-over to layer 2: an ordinary 128-byte output would land in a buffer that held 96-byte lines)
+    const bool l96 = g_l1_lines96 && planes == 3 && split0;
+    if (planes == 3 && ws_layout_switch(workspace, l96 ? 1 : 0)) {
+        const size_t nbytes = p.buf[0][3] - p.buf[0][0];           // the three rotating stage-0 buffers
+        if (hipMemsetAsync(ws + p.buf[0][0], 0, nbytes, st) != hipSuccess) return WSI_EFAULT;
+    }
+    // byte offset of image n0 inside a PF buffer of stage s
+    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * (s == 0 && l96 ? 3 : bpc); };
+    // ... and inside one phase image of stage 0's phase-split output (a PF tensor of stage 1's map size, 64 channels)
+    auto split_off = [&](int n0) { return (size_t)n0 * (p.sh[1] + 1) * (p.sw[1] + 1) * p.sc[0] * bpc; };
+
     int l1_out = 0;                                    // buffer index holding layer1's output
     for (int n1 = 0; n1 < n; n1 += c1) {
         const int nn1 = n - n1 < c1 ? n - n1 : c1;
         for (int n0 = n1; n0 < n1 + nn1; n0 += cs) {
             const int nn = n1 + nn1 - n0 < cs ? n1 + nn1 - n0 : cs;
             const int pi_ = prof_open(st, 4, 2.0 * nn * (h / 2) * (w / 2) * 64.0 * 147.0);
-            rc = wsi_stem_conv7x7_bn_relu_maxpool(in_f32 ? in_f32 + (size_t)n0 * 3 * h * w : nullptr, slide, pitch, slide_h,
-                                                  slide_w, tile_xy ? tile_xy + 2 * n0 : nullptr, lut, wt->stem_w, wt->stem_b,
-                                                  wt->stem_w_u8, wt->stem_b_u8, wt->norm,
-                                                  nn, h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0] + img_off(0, n0),
-                                                  planes, st);
+            rc = stem_run(in_f32 ? in_f32 + (size_t)n0 * 3 * h * w : nullptr, slide, pitch, slide_h,
+                          slide_w, tile_xy ? tile_xy + 2 * n0 : nullptr, lut, wt->stem_w, wt->stem_b,
+                          wt->stem_w_u8, wt->stem_b_u8, wt->norm,
+                          nn, h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0] + img_off(0, n0),
+                          planes, st, l96 ? 1 : 0);
             prof_close(st, pi_);
             if (rc) return rc;
         }
@@ -819,14 +867,18 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             const int m = (cur + 1) % 3, o = (cur + 2) % 3;
             char *x = ws + p.buf[0][cur] + img_off(0, n1), *mid = ws + p.buf[0][m] + img_off(0, n1),
                  *out = ws + p.buf[0][o] + img_off(0, n1);
-            PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
-                                                                     H1, W1, 64, 64, 1, 1, planes, st));
+            const int f_in = l96 ? CONV_IN96 : 0, f_res = l96 ? CONV_RESID96 : 0;
+            PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
+                                                              H1, W1, 64, 64, 1, 3, 1, planes, st, -1, 0, 0, nullptr, 0, nullptr, nullptr,
+                                                              f_in | (l96 ? CONV_OUT96 : 0)));
             if (b == 1 && split0) {                    // layer1's output feeds only the stride-2 entry of layer2
                 PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, ws + p.buf[0][3] + split_off(n1), x, wt->conv_w[3], wt->conv_b[3], nn1, H1, W1, 64,
-                                                                  64, 1, 3, 1, planes, st, -1, 1, pf_alloc_pixels(cap, H1 / 2, W1 / 2)));
-            } else {
-                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, wsi_conv3x3_bn_act(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
-                                                                         nn1, H1, W1, 64, 64, 1, 1, planes, st));
+                                                                  64, 1, 3, 1, planes, st, -1, 1, pf_alloc_pixels(cap, H1 / 2, W1 / 2), nullptr, 0, nullptr,
+                                                                  nullptr, f_in | f_res));
+            } else {                                   // (the stage's last conv writes 128-byte lines: layer 2, taps and skips read those)
+                PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
+                                                                  nn1, H1, W1, 64, 64, 1, 3, 1, planes, st, -1, 0, 0, nullptr, 0, nullptr, nullptr,
+                                                                  f_in | f_res | (l96 && b == 0 ? CONV_OUT96 : 0)));
             }
             cur = o;
         }

@@ -145,6 +145,11 @@ enum : int {
     CONV_XCD_ORDER = 1,        // the channel blocks of one pixel tile get workgroup ids 8 apart (same XCD / L2)
     CONV_XCD_RANGES = 2,       // every XCD walks a contiguous range of pixel tiles (neighbours share halo rows in its L2)
     CONV_RESID_DIRECT = 4,     // A/B: residual read straight from memory instead of LDS-DMA staging
+    // 96-byte activation lines (mode 3; the trunk's 64-channel layer 1, which is HBM-bound): the line in memory is
+    // [fp16 plane 64 B][lo6 dwords 0-3][lo6 dwords 4-5, scale_lo, scale_hi] - the hi6 plane, which is the fp6 image of the fp16
+    // plane, is not stored; a consumer rebuilds it in LDS after its slab has landed (conv_dev.h mx96_rebuild_hi6), where lines
+    // keep their 128-byte pitch.  Pixel stride 3 bytes per channel.
+    CONV_IN96 = 16, CONV_OUT96 = 32, CONV_RESID96 = 64,
     CONV_ABL_NO_STORE = 1 << 8, CONV_ABL_DISPATCH_ONLY = 1 << 9, CONV_ABL_NO_MAINLOOP = 1 << 10, CONV_NONTEMPORAL = 1 << 11,
     CONV_WCOPIES_SHIFT = 16,   // bits 16-19: back-to-back copies of the packed weights minus one
 };
@@ -172,6 +177,7 @@ static inline __device__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 // mode 3 helpers ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
+typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
 typedef __attribute__((ext_vector_type(32))) float f32x32;
 // E8M0 exponent byte s of a block with largest magnitude amax: the smallest s with amax / 2^(s-127) <= 7.75, i.e. the
 // largest element lands in fp6's top binade [4, 7.5] (values in (7.5, 7.75] saturate to 7.5: an error below the top

@@ -89,6 +89,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gather_kernel(ConvArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
+// Study builds: where a wave of the wide kernel spends its cycles (tools/wide_stamps.py).  s_memtime stamps around the
+// phases, summed over the waves of a launch: [0] waves, [1] lifetime, [2] tile set-up, [3] first line's slab + weights
+// (prologue), [4] later lines' slab waits, [5] tap-end waits (weight DMA + barrier), [6] tail (extra K segment, residual,
+// encode, stores).  The multiply phases are the rest.
+#ifdef WSI_STUDY
+__device__ unsigned long long g_wide_stamps[8];
+#define WSTAMP(...) __VA_ARGS__
+extern "C" int wsi_study_wide_stamps(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wide_stamps), sizeof(g_wide_stamps)) != hipSuccess) return WSI_EFAULT;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamps), z, sizeof(z)) != hipSuccess) return WSI_EFAULT;
+    }
+    return WSI_OK;
+}
+#else
+#define WSTAMP(...)
+#endif
+
 // --------------------------------------------------------------------------------------------
 // Slab kernel, software-pipelined form.  Per 128-byte line the nine taps are straight-line code:
 //   * weight fragments come through buffer loads (scalar offset per tap, no address VALU) into a
@@ -115,6 +134,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     constexpr int RESID_NBUF = MT < 2 ? MT : 2;               // residual tiles per batch and wave (mode 3; launch_slab3 sizes the LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     if (CONV_STUDY(a, CONV_ABL_DISPATCH_ONLY)) return;         // study builds: dispatch cost only
+    WSTAMP(const unsigned long long st_begin = __builtin_readcyclecounter(); unsigned long long st_pro = 0, st_line = 0, st_tap = 0, st_a = 0;)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
@@ -141,7 +161,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const int P = a.gi.P;
     const int ntile = nb * WN + wn;
     const int NC = CONV_STUDY(a, CONV_ABL_NO_MAINLOOP) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // study builds: epilogue only
-    const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
+    const bool in96 = PLANES == 3 && (a.flags & CONV_IN96);   // 96-byte input lines (common.h): 3 bytes per channel in memory, 128-byte lines in LDS
+    const size_t in_pixstride = (size_t)a.gi.C * (in96 ? 3 : PFmt<PLANES>::BPC);
+    const int in_line = in96 ? 96 : 128;
     int xoff[MT], qs[MT];                                     // slab-local pixel / PF position of each tile row
     bool valid[MT];
     int slab0, npieces;
@@ -175,9 +197,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.in + slab_byte0), 0, (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000);
     int xvoff;
+    bool xact = true;                                         // 96-byte lines: the lanes of the two hi6 slots fetch nothing
     {
         const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
-        xvoff = Pl * (int)in_pixstride + sl * 16;
+        xvoff = Pl * (int)in_pixstride + (in96 ? mx96_piece(sl) : sl) * 16;
+        if (in96) xact = mx96_stored(sl);
     }
     // study hook (tools/tune_conv.py --wcopies): bits 10-13 of relu = number of back-to-back copies of the packed
     // weights minus one; workgroups spread over the copies (do hot weight lines serialise on few L2 channels?)
@@ -214,7 +238,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         }
     };
 
+    WSTAMP(const unsigned long long st_setup = __builtin_readcyclecounter();)
     for (int c = 0; c < NC; ++c) {
+        WSTAMP(st_a = __builtin_readcyclecounter();)
         const int sline = c * 9 * 4096;
         int Pc = P;                                           // opaque per line: stops LICM from keeping all
         asm volatile("" : "+s"(Pc));                          // 36 tap/tile LDS addresses live in registers
@@ -225,9 +251,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         // term ((Pl >> 1) & 7) of a lane does not depend on the round - one per-lane byte offset (computed once per tile),
         // everything else scalar (r02: the 64-bit per-piece address arithmetic was ~10 % of this kernel's vector instructions)
         for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-            dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
+            if (xact) dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a; st_a = __builtin_readcyclecounter();)
+        if (in96) {                                           // the slab has landed: rebuild its hi6 plane in place
+            mx96_rebuild_hi6(smem, npieces >> 3, tid, NTHREADS);
+            __syncthreads();
+        }
+        WSTAMP(st_tap += __builtin_readcyclecounter() - st_a;)
         xload_m(xf[0], xoff[0], 0);                           // step (t=0, mt=0): toff(0) = 0
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -265,6 +297,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
             }
         }
     }
+    WSTAMP(const unsigned long long st_loop_end = __builtin_readcyclecounter();)
     if constexpr (PLANES == 3) {
         if (a.resid) __syncthreads();                         // every wave is done reading pixel fragments: slab memory becomes
         conv_tail_mx<1, MT, RESID_NBUF>(a, acc, qs, valid, ntile, lane, smem + wave * (RESID_NBUF * 4096), slab0);   // the waves' residual staging
@@ -276,6 +309,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         }
         conv_epilogue_q<MT, PLANES>(a, acc[0], qs, valid, ntile, lane, scratch);
     }
+#ifdef WSI_STUDY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {                                          // (same slots as the wide kernel; [5] = the hi6 rebuild passes here)
+        const unsigned long long st_end = __builtin_readcyclecounter();
+        atomicAdd(&g_wide_stamps[0], 1ull);
+        atomicAdd(&g_wide_stamps[1], st_end - st_begin);
+        atomicAdd(&g_wide_stamps[2], st_setup - st_begin);
+        atomicAdd(&g_wide_stamps[3], st_pro);
+        atomicAdd(&g_wide_stamps[4], st_line);
+        atomicAdd(&g_wide_stamps[5], st_tap);
+        atomicAdd(&g_wide_stamps[6], st_end - st_loop_end);
+    }
+#endif
 }
 
 // exact largest slab (pixels) over the dense tiles of BM real pixels
@@ -322,25 +368,6 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
 }
 
-
-// Study builds: where a wave of the wide kernel spends its cycles (tools/wide_stamps.py).  s_memtime stamps around the
-// phases, summed over the waves of a launch: [0] waves, [1] lifetime, [2] tile set-up, [3] first line's slab + weights
-// (prologue), [4] later lines' slab waits, [5] tap-end waits (weight DMA + barrier), [6] tail (extra K segment, residual,
-// encode, stores).  The multiply phases are the rest.
-#ifdef WSI_STUDY
-__device__ unsigned long long g_wide_stamps[8];
-#define WSTAMP(...) __VA_ARGS__
-extern "C" int wsi_study_wide_stamps(unsigned long long* out8, int reset) {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wide_stamps), sizeof(g_wide_stamps)) != hipSuccess) return WSI_EFAULT;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamps), z, sizeof(z)) != hipSuccess) return WSI_EFAULT;
-    }
-    return WSI_OK;
-}
-#else
-#define WSTAMP(...)
-#endif
 
 // --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
@@ -1056,6 +1083,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
     if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 90)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
+    if ((a.flags & CONV_IN96) && !((cfg >= 20 && cfg < 40) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // 96-byte input lines: slab3 kernels only
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
     if (cfg >= 70 && cfg < 90) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
     // cfg 90: 512 px x 32 couts (8 x 1 waves, two pixel tiles each) for 32-channel outputs (U-Net decoder levels 4-5)

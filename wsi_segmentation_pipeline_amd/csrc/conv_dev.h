@@ -47,6 +47,52 @@ static __device__ __forceinline__ void resid_tile_dma_buf(__amdgpu_buffer_rsrc_t
     }
 }
 
+// ---- 96-byte lines (common.h CONV_IN96 / OUT96 / RESID96) -------------------------------------------------------------
+// Logical LDS slot s of a line <-> 16-byte piece of the 96-byte memory line: slots 0-4 -> pieces 0-4, slot 6 -> piece 5,
+// slots 5 and 7 (the hi6 plane) are not stored.
+static __device__ __forceinline__ bool mx96_stored(int s) { return s != 5 && s != 7; }
+static __device__ __forceinline__ int mx96_piece(int s) { return s == 6 ? 5 : s; }
+
+// Rebuild the hi6 plane of `npix` pixel-lines of a swizzled slab image in LDS (128-byte pitch, slot s of pixel Pl at slot
+// s ^ ((Pl >> 1) & 7)) from their fp16 planes: fp6 field 2i = plane position i, field 2i + 1 = position 16 + i
+// (common.h mx6_field_of_pos), scale = the producer's scale_hi byte (dword 3 of slot 6), all 32 values by ONE
+// v_cvt_scalef32_pk32_fp6_f16 - bit-identical to what the producers' f32 path stores in a 128-byte line
+// (tools/probes/fp6_from_f16.hip: every fp16 bit pattern, every scale).  One thread per pixel-line; the caller fences with
+// barriers on both sides.
+static __device__ __forceinline__ void mx96_rebuild_hi6(char* slab, int npix, int tid, int nthreads) {
+    for (int Pl = tid; Pl < npix; Pl += nthreads) {
+        const int key = (Pl >> 1) & 7;
+        char* line = slab + Pl * 128;
+        unsigned D[16];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const u32x4 d = *(const u32x4*)(line + ((s4 ^ key) << 4));
+            D[4 * s4] = d[0]; D[4 * s4 + 1] = d[1]; D[4 * s4 + 2] = d[2]; D[4 * s4 + 3] = d[3];
+        }
+        const int sh = (int)(*(const unsigned*)(line + ((6 ^ key) << 4) + 12) & 255u);
+        u32x16 e;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)                          // register k = {position k, position 16 + k}
+            e[k] = __builtin_amdgcn_perm(D[8 + (k >> 1)], D[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u);
+        u32x6 q;
+        const float scale = sh ? mx_scale_value(sh) : 1.f;
+        asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(q) : "v"(e), "v"(scale));
+        *(u32x4*)(line + ((5 ^ key) << 4)) = u32x4{q[0], q[1], q[2], q[3]};
+        *(u32x4*)(line + ((7 ^ key) << 4)) = u32x4{q[4], q[5], (unsigned)sh, 0u};
+    }
+}
+
+// resid_tile_dma_buf for a residual stored in 96-byte lines: the lanes of the two hi6 slots stay idle
+static __device__ __forceinline__ void resid_tile_dma_buf96(__amdgpu_buffer_rsrc_t rs, int q_rel, int pixstride, int line_off, int lane, char* dst) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pp = 8 * j + (lane >> 3);
+        const int q = __shfl(q_rel, pp);
+        const int sl = (lane & 7) ^ ((pp >> 1) & 7);
+        if (mx96_stored(sl)) dma16_buf(rs, dst + j * 1024, q * pixstride + mx96_piece(sl) * 16, line_off);
+    }
+}
+
 template <int MT, int PLANES>
 static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                        const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
@@ -177,11 +223,12 @@ template <int MT, int MTN = MT>
 static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                         const bool (&valid)[MT], int ntile, int lane, int mt0 = 0) {
     const int h = lane >> 5;
-    const size_t pixstride = (size_t)a.go.C * 4;
+    const bool o96 = a.flags & CONV_OUT96;                                            // 96-byte lines (ordinary PF only, never phase-split)
+    const size_t pixstride = (size_t)a.go.C * (o96 ? 3 : 4);
     const float lo_clamp = a.relu ? 0.f : -65504.f;
 #pragma unroll
     for (int mt = mt0; mt < mt0 + MTN; ++mt) {
-        const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * 128;
+        const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * (o96 ? 96 : 128);
         f32x16 v = acc[mt];
         f32x16 hi, lo;
         f16x8 hv[2];
@@ -209,8 +256,13 @@ static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x1
             char* ol = (char*)a.out + (a.out_split_pixels ? pf_out_offset(a.go, a.out_split_pixels, qs[mt], pixstride) + (size_t)ntile * 128 : loff);
             *(f16x8*)(ol + 32 * h) = hv[0];
             *(f16x8*)(ol + 32 * h + 16) = hv[1];
-            *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
-            *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
+            if (!o96) {
+                *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
+                *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
+            } else if (h == 0) {                                                      // the lo6 plane and both scales; hi6 is rebuilt by the reader
+                *(u32x4*)(ol + 64) = u32x4{q[0], q[1], q[2], q[3]};
+                *(u32x4*)(ol + 80) = u32x4{q[4], q[5], (unsigned)sl, (unsigned)sh};
+            }
         }
     }
 }
@@ -237,7 +289,8 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
         return;
     }
     const int h = lane >> 5, l31 = lane & 31;
-    const int pixstride = a.go.C * 4;
+    const bool r96 = a.flags & CONV_RESID96;                    // the residual tensor has 96-byte lines
+    const int pixstride = a.go.C * (r96 ? 3 : 4);
     // the residual from the slab's first pixel on (slab0 = the workgroup's first input pixel = a pixel of the residual too)
     const size_t rbase = (size_t)slab0 * pixstride, rbytes = (size_t)pf_alloc_pixels(a.go.N, a.go.H, a.go.W) * pixstride;
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.resid + rbase), 0,
@@ -266,7 +319,8 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
         const int nt = k / MT, mt = k % MT;
         int qr = qs[mt] - slab0;                                // (rows past the end repeat the tile's last pixel: a real one)
         asm volatile("" : "+v"(qr));                            // opaque: offsets are rebuilt per batch, not kept alive across the encodes
-        resid_tile_dma_buf(rrs, qr, pixstride, (ntile0 + nt) * 128, lane, scratch + (k % NBUF) * 4096);
+        if (r96) resid_tile_dma_buf96(rrs, qr, pixstride, (ntile0 + nt) * 96, lane, scratch + (k % NBUF) * 4096);
+        else resid_tile_dma_buf(rrs, qr, pixstride, (ntile0 + nt) * 128, lane, scratch + (k % NBUF) * 4096);
     };
     const int xb = l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
 #pragma unroll
@@ -280,6 +334,10 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
             bf16x8 x[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(t + (xb ^ (f << 5)));
+            if (r96 && h) {                                         // 96-byte lines carry no hi6 plane: the identity's lo6 half (zeros)
+                x[2] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});   // multiplies it anyway, but a stale scale byte could be NaN
+                x[3] = x[2];
+            }
             acc[k / MT][k % MT] = mfma_mx6(acc[k / MT][k % MT], iw, x);
         }
         if (b0 + NBUF < T) {

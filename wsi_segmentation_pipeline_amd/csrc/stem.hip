@@ -181,6 +181,7 @@ struct StemPoolArgs {
     StemArgs s;              // s.out unused
     void* out_pf;            // PF (H/4, W/4, 64)
     int rows_per_seg;        // pooled rows per workgroup
+    int out96;               // OUT == 3: 96-byte output lines (common.h CONV_OUT96)
 };
 
 constexpr int SP_COLS = 70;                  // input columns per strip (2*31 + 8: the widest lane's 16-byte read)
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
     for (int r = 0; r < 16; ++r) carry[r] = 0.f;
     const bool col_ok = (c0 + l31) >= 0 && (c0 + l31) < Wc && (even || l31 < 31);
     const int lc = (even || l31 < 31) ? l31 : 30;                       // odd layout: lane 31 is idle, keep its reads inside the row
-    const size_t pixstride = (size_t)64 * PFmt<OUT>::BPC;
+    const bool o96 = OUT == 3 && A.out96;
+    const size_t pixstride = (size_t)64 * (o96 ? 3 : PFmt<OUT>::BPC);
     PFGeom go = pf_geom(a.N, Hp, Wp, 64);
 
     // every wave of the workgroup makes the same number of trips (one barrier each); strips with fewer rows idle at the end
@@ -500,11 +502,16 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 swap32_halves(lo, hi);
                 const u32x6 q = mx6_pack32(lo, hi, sb ? mx_scale_value(sb) : 1.f);
                 if (store) {                                                        // line order: common.h mx_line_pos / mx6_field_of_pos
-                    char* ol = o + wave * 128;
+                    char* ol = o + wave * (o96 ? 96 : 128);
                     *(f16x8*)(ol + 32 * h) = hv[0];
                     *(f16x8*)(ol + 32 * h + 16) = hv[1];
-                    *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
-                    *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
+                    if (!o96) {
+                        *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
+                        *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
+                    } else if (h == 0) {                                            // lo6 plane + both scales (conv_dev.h conv_epilogue_mx)
+                        *(u32x4*)(ol + 64) = u32x4{q[0], q[1], q[2], q[3]};
+                        *(u32x4*)(ol + 80) = u32x4{q[4], q[5], (unsigned)sl, (unsigned)sh};
+                    }
                 }
             } else if (store) {
 #pragma unroll
@@ -533,10 +540,10 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
 }
 
 int g_stem_shared_weights = 1;                        // A/B: wsi_stem_set_mode(fused = 3) selects the one-strip form (weights in registers)
-int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st) {
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96) {
     if (a.H % 4 || a.W % 4 || a.N <= 0 || planes < 1 || planes > 3 || rows_per_seg <= 0) return WSI_EINVAL;
     StemPoolArgs A;
-    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg;
+    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg; A.out96 = out96;
     const int Hp = a.H / 4, Wp = a.W / 4;
     const long long grid = (long long)a.N * (Wp <= 16 ? 1 : (Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);   // strips, see kernel
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
