@@ -325,9 +325,21 @@ def run_rank(args):
         roofline_l1 = {'kernel': ('layer1_block_kernel (2 launches per batch: one fused 64-channel BasicBlock each)' if fusedk else
                                   'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)'), 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                       'traffic': pmc_bytes('layer1_block' if fusedk else 'conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
+                       'traffic': None if lines96 else pmc_bytes('layer1_block' if fusedk else 'conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
                        'algorithmic_bytes_per_launch': round(alg), 'line_bytes': 96 if lines96 else 128,
                        'avg_launch_ms': round(l1['avg_ms'], 4), 'tflops': round(l1['tflops'], 2)}
+        if lines96 and tj:
+            # FETCH_SIZE is uncalibrated for reads of 96-byte lines (MI355X_MICROARCH.md: the x2 rule holds for wide coalesced reads;
+            # tools/probes/fetch_calib96 counts x1.03 when a pixel's two lines are fetched back to back, sector arithmetic for the
+            # kernel's own order gives ~x1.2): no `traffic` figure, the exact WRITE_SIZE and the raw FETCH_SIZE instead
+            sel = [v for k_, v in tj['kernels'].items() if 'conv3x3s1_slab3_kernel<4, 2, 2' in k_]
+            if sel:
+                nl = sum(v['launches'] for v in sel)
+                sc = eff_batch / 1000.0
+                roofline_l1['traffic_parts'] = {
+                    'write_bytes_per_launch': round(sum(v['write_bytes_per_launch'] * v['launches'] for v in sel) / nl * sc),
+                    'fetch_size_raw_bytes_per_launch': round(sum(v['read_bytes_per_launch'] * v['launches'] for v in sel) / nl * sc / 2),
+                    'note': 'FETCH_SIZE uncalibrated for 96-byte-line reads (x1.03 .. x2): no total; algorithmic reads are 59 % of the algorithmic bytes'}
 
     # the same dominant kernel in single-pass bf16 (the literal dtype of BASELINE configs[1]; logit error ~2e-2, outside the
     # contract, so never the headline): one profiled pass on rank 0, outside the timed region
