@@ -37,7 +37,7 @@ PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA bf16 / fp16, MI355X_MICRO
 PEAK_HBM_GBS = 8000.0
 # BASELINE.json's metric, verbatim
 METRIC = 'patches/sec (256×256×3) whole-slide inference, 1/2/4/8 MI355X + CPU ref'
-KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool', 6: 'layer1_block_fused'}
+KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool'}
 
 
 def parse_args():
@@ -310,22 +310,19 @@ def run_rank(args):
                     'traffic_source': ('%s: rocprofv3 --pmc passes of this command at batch %s, scaled to this run\'s batch of %d (not measured in this run)' %
                                        (os.path.relpath(tpath, ROOT), tj.get('batch', 1000), eff_batch or 0)) if tj else 'not collected for this mode',
                     'avg_launch_ms': round(k['avg_ms'], 4), 'mfma_passes': passes[planes], 'precision_mode': args.mode}
-    l1 = per_kind.get('layer1_block_fused') or per_kind.get('conv3x3_s1_layer1')
+    l1 = per_kind.get('conv3x3_s1_layer1')
     if l1 and eff_batch:
-        fusedk = 'layer1_block_fused' in per_kind
         bpc = 2 if planes == 1 else 4
         tensor = eff_batch * 64 * 64 * 64 * bpc
-        # algorithmic bytes per launch: unfused conv = input + output (+ residual on every second launch) = 2.5 tensors on
-        # average; fused BasicBlock = input + output (the residual is the input, the intermediate never leaves the CU).
+        # algorithmic bytes per launch: input + output (+ residual on every second launch) = 2.5 tensors on average.
         # r03, mx: stem output and layer-1 tensors are stored in 96-byte lines (3 of the 4 bytes per channel),
         # except the last conv's output: (4 inputs + 3 outputs + 2 residuals) x 0.75 + 1 output = 7.75 tensors over 4 launches
-        lines96 = planes == MX and not (args.s2 >= 0 and args.s2 & 16384) and not fusedk
-        alg = (2.0 if fusedk else 7.75 / 4 if lines96 else 2.5) * tensor
+        lines96 = planes == MX and not (args.s2 >= 0 and args.s2 & 16384)
+        alg = (7.75 / 4 if lines96 else 2.5) * tensor
         gbs = alg / (l1['avg_ms'] * 1e-3) / 1e9
-        roofline_l1 = {'kernel': ('layer1_block_kernel (2 launches per batch: one fused 64-channel BasicBlock each)' if fusedk else
-                                  'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)'), 'bound': 'hbm',
+        roofline_l1 = {'kernel': 'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                       'traffic': None if lines96 else pmc_bytes('layer1_block' if fusedk else 'conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
+                       'traffic': None if lines96 else pmc_bytes('conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
                        'algorithmic_bytes_per_launch': round(alg), 'line_bytes': 96 if lines96 else 128,
                        'avg_launch_ms': round(l1['avg_ms'], 4), 'tflops': round(l1['tflops'], 2)}
         if lines96 and tj:
