@@ -117,7 +117,8 @@ int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* 
  * (default: every stride-1 layer), +2048 the strided blocks' 1x1 downsample as its own tensor + residual instead of an extra K
  * segment of the block's second conv (mode 3), +4096 layer-1 kernel without paired-tile LDS addressing, +16384 the trunk keeps
  * 128-byte lines for the stem output and the layer-1 tensors (mode 3 default: 96-byte lines there - the hi6 plane is rebuilt
- * in LDS by the layer-1 kernel; bit-identical results).  Process-wide. */
+ * in LDS by the layer-1 kernel; bit-identical results), +32768 the wide stride-2 kernel with 128 instead of 256 output channels
+ * per workgroup on the layer-3 / layer-4 entries (mode 3; bit-identical).  Process-wide. */
 int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */

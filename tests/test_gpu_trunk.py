@@ -250,7 +250,7 @@ def test_ab_switches_agree(dev, sd):
         try:
             # (+2048: the strided blocks' downsample as its own tensor + residual instead of folded into the second conv; +4096:
             #  layer-1 kernel without paired-tile addressing - that one must not change a bit)
-            for mode in (3, 1 + 8, 1 + 16, 1 + 32, 1 + 128, 1 + 256, 1 + 512, 3 + 32 + 128 + 256, 1 + 2048, 1 + 2048 + 4096):
+            for mode in (3, 1 + 8, 1 + 16, 1 + 32, 1 + 128, 1 + 256, 1 + 512, 3 + 32 + 128 + 256, 1 + 2048, 1 + 2048 + 4096, 1 + 16384, 1 + 32768):
                 native.check(lib.wsi_conv_set_mode(mode), 'conv mode')
                 alt = eng.forward_f32(x, logits=True)[1].clone()
                 err = float((alt - base).abs().max())
@@ -359,3 +359,25 @@ def test_96_byte_layer1_lines_are_bit_identical(dev, sd):
         for a, b, c in zip(new, old, again):
             assert torch.equal(a, b) and torch.equal(a, c), (th, tw)
         assert torch.equal(tap1, tap1_old)
+
+
+def test_256_cout_stride2_workgroups_are_bit_identical(dev, sd):
+    """conv3x3s2_wide_kernel<.., NT = 4> (256 px x 256 couts per workgroup on the layer-3 / layer-4 entries, one step per barrier,
+    two 32 KB weight stages) sums every output in the same order as the 128-cout form (wsi_conv_set_mode + 32768): identical bits,
+    on 256x256 tiles (dense 16x16 / 8x8 output maps) and 64x64 crops (4x4 / 2x2: the non-dense form)."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    g = torch.Generator(device=dev).manual_seed(23)
+    eng = TrunkEngine(sd, dev, planes=3, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=9)
+    for t, n in ((256, 9), (64, 7)):
+        slide = torch.randint(0, 256, (t * 3, t * 3, 3), dtype=torch.uint8, device=dev, generator=g)
+        xy = torch.tensor([[t * (i % 3), t * (i // 3)] for i in range(n)], dtype=torch.int32, device=dev)
+        new = [v.clone() for v in eng.forward_tiles(slide, xy, t, t, feat=True, logits=True, fmap=True)]
+        try:
+            native.check(lib.wsi_conv_set_mode(1 + 32768), 'conv mode')
+            old = eng.forward_tiles(slide, xy, t, t, feat=True, logits=True, fmap=True)
+            for a, b in zip(new, old):
+                assert torch.equal(a, b), t
+        finally:
+            lib.wsi_conv_set_mode(1)

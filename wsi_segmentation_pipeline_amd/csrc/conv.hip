@@ -809,19 +809,24 @@ static int launch_s2slab(const ConvArgs& a, hipStream_t st) {
 // phase 00: tap (1,1) + the downsample tap; 01: (1,0) (1,2); 10: (0,1) (2,1); 11: (0,0) (0,2) (2,0) (2,2).  The
 // next item's pixels are fetched while the current one multiplies (two slab buffers); waves 0-3 issue the pixel
 // DMA, waves 4-7 the weight DMA, so each wave's in-order vmcnt tracks one kind only.  One barrier per tap.
-template <int PLANES, bool DENSE, bool DS>
+// NT (r03): channel tiles per wave.  2 = the form above (workgroup = 256 px x 128 couts, 16 KB weight stages in a ring of four, units of
+// up to two steps between barriers).  4 (DS = false only: 128 accumulator registers) = 256 px x 256 couts: every pixel buffer feeds twice
+// the MFMAs - half the slab DMA pieces and pixel-fragment reads per MFMA on the layer-3 / layer-4 entries - with 32 KB weight stages
+// in a ring of two, one step per unit.
+template <int PLANES, bool DENSE, bool DS, int NT = 2>
 __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 2, NT = 2, BM = 256;
-    constexpr int WBUF = 16384, XB = 45056;                   // X: up to 352 pixels (256 real ones + their pads + P + 1), whole DMA rounds
-    constexpr int NWB = 4;                                    // weight ring: the next unit (<= 2 steps) is requested while this one multiplies
+    static_assert(NT == 2 || (NT == 4 && !DS), "four channel tiles per wave: no second accumulator set");
+    constexpr int MT = 2, BM = 256, NTILES = 2 * NT, ULEN = NT == 2 ? 2 : 1;
+    constexpr int WBUF = NTILES * 4096, XB = 45056;                   // X: up to 352 pixels (256 real ones + their pads + P + 1), whole DMA rounds
+    constexpr int NWB = 2 * ULEN;                             // weight ring: the next unit (<= ULEN steps) is requested while this one multiplies
     char* const wl = smem;                                    // NWB weight buffers
     char* const xl0 = smem + NWB * WBUF;                      // 2 pixel buffers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    const int nblocks = a.go.C / 128;
+    const int nblocks = a.go.C / (NTILES * 32);
     // XCD-contiguous ranges (ids are dealt round-robin to the 8 XCDs): XCD x walks workgroups [x*chunk, (x+1)*chunk) in
     // dispatch order, so the channel blocks of one pixel tile - which read the same input pixels - and neighbouring tiles'
     // halo rows meet in ONE L2 instead of being fetched by up to four (r01 PMC: 1.53x the algorithmic bytes)
@@ -857,14 +862,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     const int NC = a.gi.C / PFmt<PLANES>::CPL;
     const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)a.wpk + (size_t)(nb * 4) * NC * 9 * 4096), 0, 4 * NC * 9 * 4096, 0x00020000);
+        (void*)((const char*)a.wpk + (size_t)(nb * NTILES) * NC * 9 * 4096), 0, NTILES * NC * 9 * 4096, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)(DS ? a.wpk2 : a.wpk) + (size_t)(nb * 4) * NC * 4096), 0, 4 * NC * 4096, 0x00020000);
+        (void*)((const char*)(DS ? a.wpk2 : a.wpk) + (size_t)(nb * NTILES) * NC * 4096), 0, NTILES * NC * 4096, 0x00020000);
     const int wvoff = lane * 16;
     // weights of (line c, tap t; t == 9: downsample) -> buffer wb; wave w in 4..7 moves quarter w-4 of each channel tile
     auto wdma = [&](int c, int t, char* wb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NTILES; ++j) {
             if (t < 9) dma16_buf(wrs, wb + j * 4096 + (wave - 4) * 1024, wvoff, ((j * NC + c) * 9 + t) * 4096 + (wave - 4) * 1024);
             else dma16_buf(wrd, wb + j * 4096 + (wave - 4) * 1024, wvoff, (j * NC + c) * 4096 + (wave - 4) * 1024);
         }
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         }
     };
     auto wread = [&](bf16x8(&w)[NT][4], const char* wb) {
-        const char* src = wb + (wn * 2) * 4096 + lane * 16;
+        const char* src = wb + (wn * NT) * 4096 + lane * 16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -893,8 +898,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if constexpr (PLANES == 3) {                           // mode 3: accumulators start from the folded BN bias
-            acc_init_bias<MT>(acc[nt], a.bias, nb * 4 + wn * 2 + nt, lane);
-            if constexpr (DS) acc_init_bias<MT>(accd[nt], a.bias2, nb * 4 + wn * 2 + nt, lane);
+            acc_init_bias<MT>(acc[nt], a.bias, nb * NTILES + wn * NT + nt, lane);
+            if constexpr (DS) acc_init_bias<MT>(accd[nt], a.bias2, nb * NTILES + wn * NT + nt, lane);
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         if (g < NG) wdma(cc, STEP_TAP[j % SPL], wl + (g & (NWB - 1)) * WBUF);
     };
     if (wave < 4) xdma(0, 0, xl0);
-    else { wdma_step(0, 0); if (NSTEP[0] == 2) wdma_step(0, 1); }
+    else { wdma_step(0, 0); if (NSTEP[0] == 2 && ULEN == 2) wdma_step(0, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < NC; ++c) {
@@ -933,12 +938,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 else if (c + 1 < NC) xdma(c + 1, 0, xl0);
             }
 #pragma unroll
-            for (int kp = 0; kp < NSTEP[ph]; kp += 2) {
+            for (int kp = 0; kp < NSTEP[ph]; kp += ULEN) {
                 const int j0 = UNIT0[ph] + kp;                // first step of the unit
-                const int ulen = NSTEP[ph] - kp >= 2 ? 2 : 1;
+                const int ulen = NSTEP[ph] - kp >= ULEN ? ULEN : 1;
                 // the next unit: the rest of this phase, or the first unit of the next phase / line
                 const int jn = j0 + ulen;
-                const int nlen = (kp + 2 < NSTEP[ph]) ? 2 : (ph < 3 ? (NSTEP[ph + 1] >= 2 ? 2 : 1) : (NSTEP[0] >= 2 ? 2 : 1));
+                const int nlen = ULEN == 1 ? 1 : (kp + 2 < NSTEP[ph]) ? 2 : (ph < 3 ? (NSTEP[ph + 1] >= 2 ? 2 : 1) : (NSTEP[0] >= 2 ? 2 : 1));
                 if (wave >= 4) { wdma_step(c, jn); if (nlen == 2) wdma_step(c, jn + 1); }
 #pragma unroll
                 for (int k = 0; k < ulen; ++k) {
@@ -966,14 +971,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 }
                 // end of the unit: the weight waves wait for the next unit's stages, the pixel waves (at an item's last unit)
                 // for the next item's pixels
-                if (wave >= 4 || kp + 2 >= NSTEP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (wave >= 4 || kp + ULEN >= NSTEP[ph]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
         }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = nb * 4 + wn * 2 + nt;
+        const int ntile = nb * NTILES + wn * NT + nt;
         if constexpr (PLANES == 3) {
             conv_epilogue_mx<MT>(a, acc[nt], qs, valid, ntile, lane);
         } else {
@@ -988,21 +993,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     }
 }
 
+int g_s2_nt4 = 1;                                        // A/B (wsi_conv_set_mode +32768 off): 256-cout workgroups in the wide stride-2 kernel
 template <int PLANES>
 static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256, XB = 45056;
     const bool ds = a.out2 != nullptr;                                       // fused 1x1 downsample branch, or the 3x3 conv alone
     if (a.go.C % 128 || a.go.P > 34 || !a.in_split_pixels || (ds && (!a.wpk2 || !a.bias2)) || a.out_split_pixels) return WSI_EINVAL;
     const long long R = (long long)a.go.N * a.go.H * a.go.W;
-    const int nblocks = a.go.C / 128;
+    const bool nt4 = !ds && PLANES == 3 && g_s2_nt4 && a.go.C % 256 == 0;      // 256 couts per workgroup (r03)
+    const int nblocks = a.go.C / (nt4 ? 256 : 128);
     // dense tiles if the span of 256 real pixels (+ the largest phase back-shift) fits one pixel buffer
     ConvArgs g = a;
     g.gi = a.go;
     const long long span = dense_max_slab_pixels(g, BM) - (a.go.P + 1);          // that helper adds 2P + 2 of halo; a phase needs P + 1
     const bool dense = (span * 8 + 255) / 256 * 256 * 16 <= XB;
     const int mtiles = dense ? (int)((R + BM - 1) / BM) : (a.go.NS + BM - 1) / BM;
-    const size_t lds = 4 * 16384 + 2 * XB;
-    auto k = dense ? (ds ? conv3x3s2_wide_kernel<PLANES, true, true> : conv3x3s2_wide_kernel<PLANES, true, false>)
+    const size_t lds = 4 * 16384 + 2 * XB;                                     // (NT = 4: two stages of 32 KB)
+    auto k = nt4 ? (dense ? conv3x3s2_wide_kernel<PLANES, true, false, 4> : conv3x3s2_wide_kernel<PLANES, false, false, 4>)
+           : dense ? (ds ? conv3x3s2_wide_kernel<PLANES, true, true> : conv3x3s2_wide_kernel<PLANES, true, false>)
                    : (ds ? conv3x3s2_wide_kernel<PLANES, false, true> : conv3x3s2_wide_kernel<PLANES, false, false>);
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return WSI_EINVAL;
     ConvArgs b = a;
