@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     }
 #ifdef WSI_STUDY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {                                          // (same slots as the wide kernel; [5] = the hi6 rebuild passes here)
+    if (lane == 0 && (blockIdx.x & 63) == 0) {                // one workgroup in 64 reports (same slots as the wide kernel; [5] = the hi6 rebuild passes here)
         const unsigned long long st_end = __builtin_readcyclecounter();
         atomicAdd(&g_wide_stamps[0], 1ull);
         atomicAdd(&g_wide_stamps[1], st_end - st_begin);
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     }
 #ifdef WSI_STUDY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the stores count as tail)
-    if (lane == 0) {
+    if (lane == 0 && (blockIdx.x & 63) == 0) {                // one workgroup in 64 reports: 10^5 waves adding to seven words distort the launch
         const unsigned long long st_end = __builtin_readcyclecounter();
         atomicAdd(&g_wide_stamps[0], 1ull);
         atomicAdd(&g_wide_stamps[1], st_end - st_begin);
