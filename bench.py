@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default='mx',
                     help='parity: bf16x2 split, 3 MFMA passes (logit error 3e-5); mx: fp16 pass + MX-fp6 cross terms '
                          '(5e-4, inside the 1e-3 contract); speed: single-pass bf16 (2e-2, outside the contract)')
-    ap.add_argument('--batch', type=int, default=6200, help='tiles per trunk call, <= 51 GB of workspace (r02: 2000 -> 103.8 k, 4200 -> 105.7 k, 6200 -> 106.6 k patches/s; the drop-in engines default to 2000)')
+    ap.add_argument('--batch', type=int, default=6200, help='cap of tiles per trunk call, <= 51 GB of workspace (r02: 2000 -> 103.8 k, 4200 -> 105.7 k, 6200 -> 106.6 k patches/s; the drop-in engines default to 2000).  A cap of 6656 lets engine.batch_sizes cut 24 648 tiles into whole rounds of the chip (3 x 6 144 + 6 216): +0.2 % (r03, inside the run-to-run noise)')
     ap.add_argument('--tiles', type=int, default=10000, help='cfg2: tiles per GPU per step')
     ap.add_argument('--size', type=int, default=40000, help='cfg3: slide edge in pixels')
     ap.add_argument('--regions', type=int, default=4000, help='cfg4: region bags (16 crops of 64x64 each) in total')

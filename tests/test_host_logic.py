@@ -422,3 +422,16 @@ def test_bench_builds_eight_rank_environments(monkeypatch):
     assert {e['WORLD_SIZE'] for e in envs} == {'8'} and {e['MASTER_ADDR'] for e in envs} == {'127.0.0.1'}
     assert len({e['MASTER_PORT'] for e in envs}) == 1 and {e['HSA_ENABLE_IPC_MODE_LEGACY'] for e in envs} == {'0'}
     assert all(e['argv'] == ['--gpus', '8', '--steps', '2', '--warmup', '1'] for e in envs)
+
+
+def test_batch_sizes_respect_cap_and_cover():
+    """engine.batch_sizes: every batch <= cap, the sizes sum to n, all but the last are whole rounds (multiples of 512 tiles of
+    256^2) when that fits the cap, equal batches otherwise."""
+    from wsi_segmentation_pipeline_amd.engine import batch_sizes
+    assert batch_sizes(24648, 6200) == [6162] * 4
+    assert batch_sizes(24648, 6656) == [6144, 6144, 6144, 6216]
+    assert batch_sizes(12324, 6656) == [6144, 6180]
+    assert batch_sizes(3081, 6656) == [3081] and batch_sizes(0, 5) == [] and batch_sizes(7, 3) == [3, 3, 1]
+    for n, cap, h in ((100000, 7000, 256), (64000, 5000, 64), (999, 100, 256), (13000, 6500, 256)):
+        sz = batch_sizes(n, cap, h, h)
+        assert sum(sz) == n and max(sz) <= cap and min(sz) > 0

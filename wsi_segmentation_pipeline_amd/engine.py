@@ -47,6 +47,24 @@ def _require_gpu(t, what):
                            '(no CPU fallback)' % what)
 
 
+def batch_sizes(n, cap, h=256, w=256):
+    """Batch sizes (each <= cap) for n images of h x w.  Several batches are sized in whole ROUNDS of the chip where that fits the
+    cap: a batch of q = 512 * 256^2 / (h w) images gives every trunk launch a whole number of workgroup rounds (layer 4: one
+    workgroup per 256^2-pixel image and channel block, 512 resident), so all batches but the last are multiples of q and the last
+    takes the rest (24 648 tiles, cap 6 656: 3 x 6 144 + 6 216 - a 12.04-round launch runs 13 rounds, r03: +1 % on cfg3).
+    Otherwise equal sizes without a short tail, as before."""
+    n, cap = int(n), max(1, int(cap))
+    k = max(1, -(-n // cap))
+    if k == 1:
+        return [n] if n else []
+    q = max(1, 512 * 65536 // max(h * w, 1))
+    base = int(round(n / k / q)) * q
+    if base >= q and n - base * (k - 1) <= cap and n - base * (k - 1) > 0 and base <= cap:
+        return [base] * (k - 1) + [n - base * (k - 1)]
+    mb = -(-n // k)                                        # equal-sized batches: ceil(n / ceil(n / cap))
+    return [min(mb, n - i) for i in range(0, n, mb)]
+
+
 class TrunkEngine:
     """ResNet-18 trunk (stem + layer1..4) of the reference ``resnets_shift.ResNet`` on HIP kernels,
     with an optional Linear(512->K) head fused after the average pool (``fc0`` or ``Classifier``).
@@ -218,11 +236,14 @@ class TrunkEngine:
 
     def _batched(self, n, run, h=256, w=256):
         """Split n images into max_batch chunks; with several chunks, alternate them over the side streams."""
-        mb = self.max_batch if self.max_batch else max(1, int(2000 * 65536 // max(h * w, 1)))
-        mb = -(-n // max(1, -(-n // mb)))                  # equal-sized batches (no short tail): ceil(n / ceil(n / mb))
-        starts = list(range(0, n, mb))
+        cap = self.max_batch if self.max_batch else max(1, int(2000 * 65536 // max(h * w, 1)))
+        sizes = batch_sizes(n, cap, h, w)
+        starts = [sum(sizes[:j]) for j in range(len(sizes))]
+        if len(sizes) > 1:                                  # plan every slot's workspace for the largest batch once (the last one)
+            for slot in range(max(1, len(self._streams)) if self._streams else 1):
+                self._workspace(max(sizes), h, w, slot)
         if len(starts) == 1 or not self._streams:
-            outs = [run(i, min(mb, n - i), 0) for i in starts]
+            outs = [run(i, m, 0) for i, m in zip(starts, sizes)]
         else:
             cur = torch.cuda.current_stream()
             ready = torch.cuda.Event()
@@ -232,7 +253,7 @@ class TrunkEngine:
                 st = self._streams[j % len(self._streams)]
                 st.wait_event(ready)
                 with torch.cuda.stream(st):
-                    outs.append(run(i, min(mb, n - i), j % len(self._streams)))
+                    outs.append(run(i, sizes[j], j % len(self._streams)))
             for st in self._streams:
                 cur.wait_stream(st)
             for o in outs:                                  # tensors were allocated on side streams
