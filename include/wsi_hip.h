@@ -155,6 +155,10 @@ typedef struct {
 size_t wsi_trunk_workspace_bytes(int n, int h, int w, int planes);
 /* zero-fills the workspace for the (n,h,w,planes) plan; call once before the first forward */
 int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, void* stream);
+/* call before freeing a workspace: the library forgets what it remembered about that address (the line layout its stage-0
+ * buffers last held), so a later allocation at the same address starts clean.  The reference has no counterpart: its
+ * activations are torch tensors freed by the allocator (/root/reference/utils/eval.py:190-215 allocates per batch). */
+int wsi_trunk_workspace_release(void* workspace);
 /* workspace_n: the image count the workspace was sized and initialised for (>= n; 0 means n): one workspace planned
  * for the largest batch serves every smaller one (ragged last batches, variable bag counts) without re-initialisation. */
 int wsi_trunk_forward(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide,

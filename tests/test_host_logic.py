@@ -435,3 +435,90 @@ def test_batch_sizes_respect_cap_and_cover():
     for n, cap, h in ((100000, 7000, 256), (64000, 5000, 64), (999, 100, 256), (13000, 6500, 256)):
         sz = batch_sizes(n, cap, h, h)
         assert sum(sz) == n and max(sz) <= cap and min(sz) > 0
+
+
+# ------------------------------------------------------------------------------ precision='auto': one decision per slide and world
+class _FakeTrunk:
+    """Stands in for a TrunkEngine on the CPU: logits = per-slide, per-mode constants, calls are recorded."""
+    def __init__(self, name, planes, log):
+        self.name, self.planes, self.head_k, self.log = name, planes, 4, log
+
+    def forward_tiles(self, slide, xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
+        self.log.append((self.name, int(slide[0, 0, 0]), int(xy.shape[0])))
+        # slide "1" is benign, slide "2" is hot ON RANK 1 ONLY (slide[0, 0, 1] carries the rank): mx is 1e-3 off parity there
+        hot = int(slide[0, 0, 0]) == 2 and int(slide[0, 0, 1]) == 1
+        off = 1e-3 if (self.name == 'mx' and hot) else 0.0
+        lg = torch.full((xy.shape[0], 4), 1.0 + off)
+        return (torch.zeros(xy.shape[0], 512), lg, None)
+
+
+def _fake_auto(log):
+    from wsi_segmentation_pipeline_amd.engine import AutoTrunkEngine
+    eng = object.__new__(AutoTrunkEngine)
+    eng._par, eng._mx = _FakeTrunk('parity', 2, log), _FakeTrunk('mx', 3, log)
+    eng._dev, eng.tol, eng.probe = 'cpu', 5e-4, 4
+    eng._chosen, eng._slide_key, eng._slide_ref, eng._probed = None, None, None, None
+    eng.report = {'mode': None}
+    return eng
+
+
+def _auto_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    log = []
+    eng = _fake_auto(log)
+    modes = []
+    xy = torch.zeros((8, 2), dtype=torch.int32)
+    for sid in (1, 2, 1):                                   # benign, hot on rank 1 only, benign again (a NEW tensor each time)
+        slide = torch.zeros((4, 4, 3), dtype=torch.uint8)
+        slide[0, 0, 0], slide[0, 0, 1] = sid, rank
+        # the sequence slide.infer_slide_cls runs: local probe, max over the ranks, decide, forward
+        eng.decide(S.allreduce_max(eng.probe_tiles(slide, xy, 256, 256), 'cpu', world))
+        n0 = len(log)
+        eng.forward_tiles(slide, xy, 256, 256)
+        eng.forward_tiles(slide, xy[:3], 256, 256)          # a second chunk of the same slide
+        ran = [e for e in log[n0:]]
+        modes.append((eng.report['mode'], [r[0] for r in ran]))
+        del slide
+    q.put((rank, modes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_auto_precision_is_one_decision_per_slide_and_world():
+    """r03 advisor finding: decide() left the previous slide's key in place, so from the second slide on forward_tiles probed again
+    LOCALLY and could run another mode than the all-reduced decision (and than the `precision` report).  Two ranks, three slides,
+    probe errors that straddle tol on one rank only: every rank must run the rank-global mode, with no second probe."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_auto_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    want = [('mx', ['mx', 'mx']), ('parity', ['parity', 'parity']), ('mx', ['mx', 'mx'])]
+    assert res[0] == want and res[1] == want, res
+
+
+def test_auto_precision_does_not_trust_a_recycled_address():
+    """Direct forward_tiles callers: a new slide tensor is a new slide even when the allocator hands it the old block (same
+    data_ptr, same shape) - the engine keys on the tensor object or on a caller-supplied slide_id, never on the address."""
+    log = []
+    eng = _fake_auto(log)
+    xy = torch.zeros((8, 2), dtype=torch.int32)
+    store = torch.zeros((4, 4, 3), dtype=torch.uint8)
+    a = store[:]                                            # two tensor objects over ONE address
+    b = store[:]
+    assert a.data_ptr() == b.data_ptr() and a is not b
+    eng.forward_tiles(a, xy, 256, 256)
+    n_probe_a = sum(1 for e in log if e[2] == 4)
+    eng.forward_tiles(a, xy, 256, 256)                      # same object: no new probe
+    assert sum(1 for e in log if e[2] == 4) == n_probe_a == 2
+    eng.forward_tiles(b, xy, 256, 256)                      # same address, other object: probes again
+    assert sum(1 for e in log if e[2] == 4) == 4
+    eng.forward_tiles(store[:], xy, 256, 256, slide_id='S7')
+    eng.forward_tiles(store[:], xy, 256, 256, slide_id='S7')   # explicit id: one probe for both views
+    assert sum(1 for e in log if e[2] == 4) == 6

@@ -6,7 +6,31 @@ import json
 import sys
 from collections import defaultdict
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 out_dir, dst = sys.argv[1], sys.argv[2]
+
+
+def launch_batch(argv):
+    """Tiles per trunk launch of the profiled bench command (cfg3 unless --workload cfg2): the engine cuts the slide's tiles into
+    equal batches under the --batch cap (engine.batch_sizes), e.g. 24 648 tiles at cap 6 200 -> 6 162, at cap 1 000 -> 986
+    (r03 advisor finding: this file used to record the cap, 1000, and bench.py's scaled figure came out 1.4 % low)."""
+    from wsi_segmentation_pipeline_amd.engine import batch_sizes
+    from wsi_segmentation_pipeline_amd import slide as S
+
+    def opt(name, default):
+        return type(default)(argv[argv.index(name) + 1]) if name in argv else default
+    cap = opt('--batch', 6200)
+    if opt('--workload', 'cfg3') == 'cfg2':
+        tiles = opt('--tiles', 10000)
+    else:
+        size = opt('--size', 40000)
+        tiles = len(S.tile_grid(size, size, 256, 256, 256, 256))
+    sizes = batch_sizes(tiles, cap)
+    return sum(sizes) / len(sizes), tiles, cap
+
+
 acc = defaultdict(lambda: {'FETCH_SIZE': [], 'WRITE_SIZE': []})
 for which in ('fetch', 'write'):
     for f in glob.glob('%s/%s/*/*_counter_collection.csv' % (out_dir, which)):
@@ -25,7 +49,8 @@ for name, d in acc.items():
                  'hbm_bytes_per_launch': fetch + write}
 slab = {k: v for k, v in res.items() if 'conv3x3s1_' in k}      # slab3 + wide: all stride-1 3x3 launches
 tot_l = sum(v['launches'] for v in slab.values())
-summary = {'bench_args': sys.argv[3:], 'batch': 1000, 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 (gfx950), KiB units',
+batch, tiles, cap = launch_batch(sys.argv[3:])
+summary = {'bench_args': sys.argv[3:], 'batch': batch, 'tiles': tiles, 'batch_cap': cap, 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH x2 (gfx950), KiB units',
            'kernels': res,
            'conv3x3_s1_hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in slab.values()) / max(tot_l, 1)}
 json.dump(summary, open(dst, 'w'), indent=1)

@@ -291,18 +291,24 @@ def predict_regions(model, iterator, metadata, label_shape, class_probs=None, ra
     with torch.no_grad():
         parts = []
         eng = model.hip_engine(dev) if world > 1 and hasattr(model, 'hip_engine') else None
-        probed = not hasattr(eng, 'probe_f32')                # precision='auto' over several ranks: ONE mode for every rank
+        if hasattr(eng, 'probe_f32'):
+            # precision='auto' over several ranks: ONE mode for every rank.  The probe is a stratified sample over this rank's
+            # WHOLE shard of bags (r03 advisor finding: probing the first batch only is the first-tiles blind spot the per-slide
+            # stratified probe was introduced to remove): up to `eng.probe` bags spread evenly over the shard, their crops
+            # sub-sampled by probe_f32; a rank without bags still takes part in the collective
+            mine_idx = list(shards[rank])
+            eng.reset()
+            err = 0.0
+            if mine_idx:
+                nb = min(int(getattr(eng, 'probe', 32)), len(mine_idx))
+                pick = sorted({mine_idx[int(round(v))] for v in np.linspace(0, len(mine_idx) - 1, nb)})
+                sample = torch.cat([im.to(dev).reshape(-1, *im.shape[2:]) for im, _ in iterator.shard(pick)])
+                err = eng.probe_f32(sample)
+            eng.decide(S.allreduce_max(err, dev, world), scope='regions')
         for images, tile_ids in mine:
             if data is None:
                 seen_ids.extend(int(t) for t in tile_ids)
-            images = images.to(dev)
-            if not probed:
-                eng.reset()
-                eng.decide(S.allreduce_max(eng.probe_f32(images.reshape(-1, *images.shape[2:])), dev, world), scope='regions')
-                probed = True
-            parts.append(model(images)[1])
-        if not probed:                                        # a rank without bags still takes part in the collective
-            eng.decide(S.allreduce_max(0.0, dev, world), scope='regions')
+            parts.append(model(images.to(dev))[1])
         num_classes = len(class_probs)
         local = torch.cat(parts) if parts else torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
         ens = B.gather_rows(local, shards, rank, world) if world > 1 else local

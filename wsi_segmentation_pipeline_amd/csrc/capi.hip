@@ -741,7 +741,7 @@ static int g_chunk_stem = 0, g_chunk_l1 = 0;   // sub-batch sizes (images); 0 = 
 // other BYTES than in the 128-byte layout, and pads are only ever zero because nobody writes them - so a workspace remembers
 // which layout its three stage-0 buffers last held, and a run in the other layout zero-fills them first (taps and the U-Net
 // encoder keep the 128-byte layout; a workspace that only ever runs one kind of call never pays).  -1 = all zero (after
-// wsi_trunk_workspace_init), 0 = 128-byte lines, 1 = 96-byte lines; an unknown workspace counts as dirty.
+// wsi_trunk_workspace_init), otherwise 2 * planes + (1 if stage 0 holds 96-byte lines); an unknown workspace counts as dirty.
 int g_l1_lines96 = 1;                           // A/B: wsi_conv_set_mode +16384 disables
 static std::mutex g_ws_mutex;
 static std::unordered_map<const void*, int> g_ws_layout;
@@ -750,7 +750,15 @@ static int ws_layout_switch(const void* ws, int want) {      // returns 1 if the
     auto it = g_ws_layout.find(ws);
     const int have = it == g_ws_layout.end() ? -2 : it->second;
     g_ws_layout[ws] = want;
-    return !(have == want || have == -1);
+    if (have == want || have == -1) return 0;
+    return (have >= 0 && have / 2 != want / 2) ? 2 : 1;      // 2: the workspace last ran another planes value - every pad may be dirty
+}
+// A workspace that is freed must be forgotten: a later allocation at the same address would inherit its layout tag (r03 advisor
+// finding) and the map would grow without bound.  Unknown pointers are fine (nothing to forget).
+int wsi_trunk_workspace_release(void* workspace) {
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    g_ws_layout.erase(workspace);
+    return WSI_OK;
 }
 
 int wsi_trunk_set_chunks(int stem_chunk, int layer1_chunk) {
@@ -839,8 +847,10 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     // the last layer-1 conv writes the ordinary (or phase-split) 128-byte form every other kernel reads
     // (only with the phase-split hand-over to layer 2: an ordinary 128-byte output would land in a buffer that held 96-byte lines)
     const bool l96 = g_l1_lines96 && planes == 3 && split0;
-    if (planes == 3 && ws_layout_switch(workspace, l96 ? 1 : 0)) {
-        const size_t nbytes = p.buf[0][3] - p.buf[0][0];           // the three rotating stage-0 buffers
+    // the tag is recorded for EVERY planes value (r03 advisor finding: a planes 1 / 2 run used to leave a stale '96-byte lines' tag,
+    // and a later mx run on the same workspace then skipped the zero-fill): tag = 2 * planes + (96-byte lines)
+    if (const int dirty = ws_layout_switch(workspace, 2 * planes + (l96 ? 1 : 0))) {
+        const size_t nbytes = dirty == 2 ? p.total - p.buf[0][0] : p.buf[0][3] - p.buf[0][0];   // the three rotating stage-0 buffers (or everything)
         if (hipMemsetAsync(ws + p.buf[0][0], 0, nbytes, st) != hipSuccess) return WSI_EFAULT;
     }
     // byte offset of image n0 inside a PF buffer of stage s
@@ -1050,14 +1060,24 @@ static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& 
                             float* logits_out, hipStream_t st) {
     const void* x = enc[0];
     int rc = WSI_OK;
+    // wsi_prof kinds of the decoder (bench.py --workload seg): 6 = decoder 3x3 conv (algorithmic FLOPs over REAL channels are the
+    // caller's business: the record carries 2 * N * H * W * cin_stored * cout_stored * 9), 7 = upsample + concat glue, 8 = 1x1 head
     for (int L = 0; L < 5 && !rc; ++L) {
         const int H = u.r_h[L], W = u.r_w[L], cin = dw->cin[2 * L], cout = dw->cout[2 * L];
+        int pi = prof_open(st, 7, 0.0);
         rc = wsi_upsample_concat_dispatch(x, L < 4 ? enc[L + 1] : nullptr, dec + u.cat[L], n, H / 2, W / 2, u.cx[L], kUnetSkipC[L], planes, st);
+        prof_close(st, pi);
+        pi = prof_open(st, 6, 2.0 * n * H * W * (double)cin * cout * 9);
         if (!rc) rc = conv_common(dec + u.cat[L], dec + u.mid[L], nullptr, dw->conv_w[2 * L], dw->conv_b[2 * L], n, H, W, cin, cout, 1, 3, 1, planes, st);
+        prof_close(st, pi);
+        pi = prof_open(st, 6, 2.0 * n * H * W * (double)cout * cout * 9);
         if (!rc) rc = conv_common(dec + u.mid[L], dec + u.out[L], nullptr, dw->conv_w[2 * L + 1], dw->conv_b[2 * L + 1], n, H, W, cout, cout, 1, 3, 1, planes, st);
+        prof_close(st, pi);
         x = dec + u.out[L];
     }
+    const int pi = prof_open(st, 8, 2.0 * n * u.r_h[4] * u.r_w[4] * (double)dw->head_cin * dw->classes);
     if (!rc) rc = wsi_unet_head_dispatch(x, n, u.r_h[4], u.r_w[4], dw->cout[9], dw->head_w, dw->head_b, dw->head_cin, dw->classes, logits_out, planes, st);
+    prof_close(st, pi);
     return rc;
 }
 
@@ -1087,8 +1107,10 @@ int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights
     a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
     a.origins = tile_xy; a.lut = lut; a.wpk = wt->stem_w; a.bias = wt->stem_b; a.out = (float*)(ws + p.stem_scratch);
     a.N = n; a.H = h; a.W = w; a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
+    const int pi = prof_open(st, 7, 0.0);                    // (glue: the unfused stem conv + its re-encode for the 128 x 128 skip)
     rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
     if (!rc) rc = wsi_nhwc_to_pf_dispatch(a.out, dec + u.x0, n, h / 2, w / 2, 64, planes, st);
+    prof_close(st, pi);
     if (rc) return rc;
     const void* enc[5] = {ws + stage_off[3], ws + stage_off[2], ws + stage_off[1], ws + stage_off[0], dec + u.x0};
     if (enc_out) {                                           // the `model.encoder(x)` surface: five fp32 NCHW maps, deepest first

@@ -4,6 +4,7 @@ PyTorch is used only as plumbing (device memory, streams); all compute goes thro
 libwsi_hip.so (include/wsi_hip.h).  There is no CPU fallback: tensors must live on a GPU.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -51,7 +52,8 @@ def batch_sizes(n, cap, h=256, w=256):
     """Batch sizes (each <= cap) for n images of h x w.  Several batches are sized in whole ROUNDS of the chip where that fits the
     cap: a batch of q = 512 * 256^2 / (h w) images gives every trunk launch a whole number of workgroup rounds (layer 4: one
     workgroup per 256^2-pixel image and channel block, 512 resident), so all batches but the last are multiples of q and the last
-    takes the rest (24 648 tiles, cap 6 656: 3 x 6 144 + 6 216 - a 12.04-round launch runs 13 rounds, r03: +1 % on cfg3).
+    takes the rest (24 648 tiles, cap 6 656: 3 x 6 144 + 6 216 - a 12.04-round launch runs 13 rounds; measured r03: +0.2 % on cfg3, inside the
+    run-to-run noise - the nearly empty thirteenth round is short).
     Otherwise equal sizes without a short tail, as before."""
     n, cap = int(n), max(1, int(cap))
     k = max(1, -(-n // cap))
@@ -169,14 +171,26 @@ class TrunkEngine:
             nbytes = self.lib.wsi_trunk_workspace_bytes(n, h, w, self.planes)
             if nbytes == 0:
                 raise ValueError('unsupported patch shape %dx%d (need multiples of 32) or batch %d' % (h, w, n))
-            self._ws.pop(key, None)                         # a smaller plan of the same shape is released first
+            self._drop_workspace(key)                       # a smaller plan of the same shape is released first
             if len(self._ws) >= 4 * max(1, len(self._streams)):   # keep the plan cache small
-                self._ws.pop(next(iter(self._ws)))
+                self._drop_workspace(next(iter(self._ws)))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             native.check(self.lib.wsi_trunk_workspace_init(_ptr(ws), n, h, w, self.planes, _stream()),
                          'wsi_trunk_workspace_init')
             ent = self._ws[key] = (ws, n)
         return ent
+
+    def _drop_workspace(self, key):
+        ent = self._ws.pop(key, None)
+        if ent is not None:                                 # the library forgets the address before the allocator can reuse it
+            self.lib.wsi_trunk_workspace_release(_ptr(ent[0]))
+
+    def __del__(self):
+        try:
+            for key in list(getattr(self, '_ws', {})):
+                self._drop_workspace(key)
+        except Exception:                                   # interpreter shutdown: the library may be gone
+            pass
 
     # ------------------------------------------------------------------ forward passes
     def _run(self, n, h, w, in_f32, slide, tile_xy, want_feat, want_logits, want_fmap, tap=None, slot=0):
@@ -300,7 +314,7 @@ class AutoTrunkEngine:
         else:
             self.report = {'mode': 'parity', 'reason': reason, 'probe_error': None}
         self._chosen = None if self._mx is not None else self._par
-        self._slide_key = None
+        self._slide_key, self._slide_ref, self._probed = None, None, None
 
     @staticmethod
     def _static_check(sd):
@@ -343,7 +357,24 @@ class AutoTrunkEngine:
     def reset(self):
         """Forget the decision: the next forward (or probe_tiles / decide pair) probes again."""
         if self._mx is not None:
-            self._chosen, self._slide_key = None, None
+            self._chosen, self._slide_key, self._slide_ref = None, None, None
+
+    def _key_of(self, slide_u8, slide_id):
+        """Identity of a slide for the one-decision-per-slide rule.  A caller-supplied `slide_id` (any hashable) wins; without one
+        the slide is the TENSOR OBJECT the caller passes (held by weak reference), never its address: the caching allocator hands a
+        new slide of the same shape the block the previous one just freed, and a (data_ptr, shape) key would then silently reuse the
+        previous slide's mode without a probe."""
+        if slide_id is not None:
+            return ('id', slide_id)
+        return ('obj', id(slide_u8))
+
+    def _same_slide(self, slide_u8, key):
+        if key != self._slide_key:
+            return False
+        if key[0] == 'id':
+            return True
+        ref = self._slide_ref
+        return ref is not None and ref() is slide_u8            # a dead or different object with a recycled id() is a new slide
 
     def _stratified(self, total):
         n = min(self.probe, int(total))
@@ -358,9 +389,11 @@ class AutoTrunkEngine:
         return (float((fm - fp).abs().max() / fp.abs().max().clamp_min(1e-30)) * 2.0, '2 x max |feat_mx - feat_parity| / max |feat|',
                 int(fp.shape[0]))
 
-    def probe_tiles(self, slide_u8, tile_xy, ph, pw):
+    def probe_tiles(self, slide_u8, tile_xy, ph, pw, slide_id=None):
         """Local probe error of mx on a stratified sample of `tile_xy` (0.0 without tiles or without an mx engine); the caller
-        all-reduces the maximum over its ranks and calls decide()."""
+        all-reduces the maximum over its ranks and calls decide().  The slide probed here is the slide the following decide()
+        fixes the mode for: forward_tiles on it (same tensor object, or same `slide_id`) does not probe again."""
+        self._probed = (self._key_of(slide_u8, slide_id), weakref.ref(slide_u8))
         if self._mx is None or int(tile_xy.shape[0]) == 0:
             return 0.0
         xy = tile_xy[self._stratified(tile_xy.shape[0])].contiguous()
@@ -376,7 +409,12 @@ class AutoTrunkEngine:
         return err
 
     def decide(self, err, scope='slide'):
-        """Fix the mode for the coming forwards from a (rank-global) probe error."""
+        """Fix the mode for the coming forwards from a (rank-global) probe error.  After a probe_tiles() the decision belongs to
+        THAT slide (r03 advisor finding: decide() used to leave the previous slide's key in place, so the first forward_tiles of
+        every slide but the first probed again locally and could override the all-reduced decision on some ranks only)."""
+        probed, self._probed = getattr(self, '_probed', None), None
+        if probed is not None:
+            self._slide_key, self._slide_ref = probed
         if self._mx is None:
             return
         ok = bool(np.isfinite(err)) and err <= self.tol
@@ -390,12 +428,12 @@ class AutoTrunkEngine:
             self.decide(self.probe_f32(x), scope='head')
         return self._chosen.forward_f32(x, feat=feat, logits=logits, fmap=fmap, tap=tap)
 
-    def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None):
-        # one decision per slide: a new slide tensor (or a reset) probes again; chunks of the same slide reuse the decision
-        key = (int(slide_u8.data_ptr()), tuple(slide_u8.shape))
-        if self._mx is not None and (self._chosen is None or (self._slide_key is not None and key != self._slide_key)):
-            self.decide(self.probe_tiles(slide_u8, tile_xy, ph, pw))
-        self._slide_key = key
+    def forward_tiles(self, slide_u8, tile_xy, ph, pw, feat=False, logits=True, fmap=False, tap=None, slide_id=None):
+        # one decision per slide: a slide this engine has not decided for (or a reset) probes first; chunks of the same slide - the
+        # same tensor object or the same caller-supplied slide_id - reuse the decision, including one made by probe_tiles + decide
+        key = self._key_of(slide_u8, slide_id)
+        if self._mx is not None and (self._chosen is None or not self._same_slide(slide_u8, key)):
+            self.decide(self.probe_tiles(slide_u8, tile_xy, ph, pw, slide_id=slide_id))
         return self._chosen.forward_tiles(slide_u8, tile_xy, ph, pw, feat=feat, logits=logits, fmap=fmap, tap=tap)
 
 

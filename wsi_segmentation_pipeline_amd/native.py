@@ -64,6 +64,7 @@ SIGNATURES = {
     'wsi_pf_unpack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'wsi_trunk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'wsi_trunk_workspace_init': (_i, [_vp, _i, _i, _i, _i, _vp]),
+    'wsi_trunk_workspace_release': (_i, [_vp]),
     'wsi_trunk_forward': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     'wsi_trunk_forward_tap': (_i, [C.POINTER(WsiTrunkWeights), _vp, _vp, _ll, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'wsi_trunk_set_chunks': (_i, [_i, _i]),
