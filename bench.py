@@ -52,9 +52,11 @@ def parse_args():
                     help="seg: the dense per-pixel mode (predict_tumorbed mode='seg': ResNet-18 encoder + U-Net decoder), --seg-tiles tiles of 256x256 per step")
     ap.add_argument('--seg-tiles', type=int, default=512)
     ap.add_argument('--seg-batch', type=int, default=128, help='seg: tiles per U-Net call (77 MB of workspace per tile)')
-    ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default='mx',
+    ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default=None,
                     help='parity: bf16x2 split, 3 MFMA passes (logit error 3e-5); mx: fp16 pass + MX-fp6 cross terms '
-                         '(5e-4, inside the 1e-3 contract); speed: single-pass bf16 (2e-2, outside the contract)')
+                         '(5e-4, inside the 1e-3 contract); speed: single-pass bf16 (2e-2, outside the contract).  Default: mx; for '
+                         '--workload seg parity (the drop-in UNetSeg default: per-pixel logits have no average pool behind them and mx '
+                         'is 3-4e-3 off at |logit| 16 there), with an mx leg reported beside it')
     ap.add_argument('--batch', type=int, default=6200, help='cap of tiles per trunk call, <= 51 GB of workspace (r02: 2000 -> 103.8 k, 4200 -> 105.7 k, 6200 -> 106.6 k patches/s; the drop-in engines default to 2000).  A cap of 6656 lets engine.batch_sizes cut 24 648 tiles into whole rounds of the chip (3 x 6 144 + 6 216): +0.2 % (r03, inside the run-to-run noise)')
     ap.add_argument('--tiles', type=int, default=10000, help='cfg2: tiles per GPU per step')
     ap.add_argument('--size', type=int, default=40000, help='cfg3: slide edge in pixels')
@@ -175,6 +177,10 @@ def run_rank(args):
         # tiles read from an HBM-resident u8 slide -> (N, 4, 256, 256) logits; each rank runs its own --seg-tiles tiles (weak scaling)
         from wsi_segmentation_pipeline_amd.unet import UNetEngine
         usd = W.make_unet_state_dict(5, classes=4)
+        # the seeded decoder ends in |logit| ~ 216 (softmax saturated everywhere); the 1e-3 contract is stated on logits of the
+        # size trained heads produce, so the final 1x1 conv is scaled to |logit| <= ~16, the magnitude of the margin families
+        for key in ('decoder.final_conv.weight', 'decoder.final_conv.bias'):
+            usd[key] = usd[key] * (16.0 / 216.0)
         eng = UNetEngine(usd, dev, planes=planes, max_batch=args.seg_batch)
         eng._streams = []
         side = int(np.ceil(np.sqrt(args.seg_tiles)))
@@ -385,6 +391,7 @@ def run_rank(args):
     # the same dominant kernel in single-pass bf16 (the literal dtype of BASELINE configs[1]; logit error ~2e-2, outside the
     # contract, so never the headline): one profiled pass on rank 0, outside the timed region
     if rank == 0 and prof_on and not args.no_bf16_leg and planes != SPEED and args.workload not in ('cfg4', 'seg'):
+        eng.release_workspaces()                               # two batches in flight = two workspaces (~51 GB each): the legs below need the room
         eng1 = TrunkEngine(sd, dev, planes=SPEED, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch)
         nsub = min(hi - lo, 2 * args.batch)
         sub = torch.from_numpy(np.ascontiguousarray(local_xy[:nsub])).to(dev)
@@ -400,6 +407,7 @@ def run_rank(args):
                              'achieved': round(k1['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                              'frac': round(k1['tflops'] / PEAK_BF16_TFLOPS, 4), 'avg_launch_ms': round(k1['avg_ms'], 4),
                              'batch': -(-nsub // max(1, -(-nsub // args.batch))), 'timed': 'outside the timed region (3 passes over %d tiles)' % nsub}
+        eng1.release_workspaces()
         del eng1
 
     # ------------------------------------------------------------------------------- CPU baseline (rank 0, N = 1)
@@ -449,6 +457,7 @@ def run_rank(args):
                     'oracle_sample_tiles': oracle_sample[1] if cpu_baseline else None,
                     'families_max': (fam or {}).get(args.mode), 'families_source': os.path.relpath(fpath, ROOT) if fam else None}
     if rank == 0 and world == 1 and planes != PARITY and not args.no_parity_leg and args.workload in ('cfg2', 'cfg3'):
+        eng.release_workspaces()
         engp = TrunkEngine(sd, dev, planes=PARITY, head=(cls['fc.0.weight'], cls['fc.0.bias']), max_batch=args.batch, streams=args.streams)
 
         def pstep():
@@ -465,6 +474,7 @@ def run_rank(args):
                       'steps': 2, 'timed': 'after the timed region, same slide and batch',
                       'max_abs_logit_diff_vs_oracle': float((outp['logits'][:oracle_sample[1]].cpu() - oracle_sample[0]).abs().max()) if cpu_baseline else None,
                       'max_abs_logit_diff_vs_headline_mode': float((outp['logits'] - out['logits']).abs().max())}
+        engp.release_workspaces()
         del engp
 
     if args.workload == 'seg' and rank == 0:
@@ -498,7 +508,24 @@ def run_rank(args):
                             'sample': 'first %d tiles of the same slide, fp32 torch CPU spec (oracle/unet_oracle.py: parity unpinned, smp absent), 1 warm-up + median of 3' % nsample,
                             'max_abs_logit_diff_vs_gpu': float((got - ref).abs().max())}
             contract = {'mode': args.mode, 'tolerance': 1e-3, 'max_abs_logit_diff_vs_oracle': cpu_baseline['max_abs_logit_diff_vs_gpu'],
-                        'oracle_sample_tiles': nsample, 'note': 'per-pixel logits of the first %d tiles against the CPU spec' % nsample}
+                        'max_abs_logit': float(ref.abs().max()), 'oracle_sample_tiles': nsample,
+                        'note': 'per-pixel logits (4 x 256 x 256 per tile) of the first %d tiles against the CPU spec; final 1x1 conv of the seeded decoder scaled by 16/216' % nsample}
+            if planes != MX:
+                # the faster mode beside it: timed after the timed region; outside the contract on this path (no average pool
+                # behind the per-pixel logits: its error is ~2.5e-4 of the largest |logit|)
+                engx = UNetEngine(usd, dev, planes=MX, max_batch=args.seg_batch)
+                ox = engx.forward_tiles(level0, sxy, TILE, TILE)
+                torch.cuda.synchronize()
+                x0 = time.perf_counter()
+                for _ in range(2):
+                    ox = engx.forward_tiles(level0, sxy, TILE, TILE)
+                torch.cuda.synchronize()
+                xdt = (time.perf_counter() - x0) / 2
+                parity_leg = {'mode': 'mx', 'value': round(args.seg_tiles / xdt, 1), 'unit': unit, 'ms_per_step': round(xdt * 1e3, 3), 'steps': 2,
+                              'timed': 'after the timed region, same slide and batch',
+                              'max_abs_logit_diff_vs_oracle': float((ox[:nsample].cpu() - ref).abs().max()),
+                              'note': 'outside the 1e-3 contract on the dense path: the drop-in UNetSeg defaults to parity'}
+                del engx, ox
 
     if rank == 0:
         line = {
@@ -545,6 +572,8 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    if args.mode is None:
+        args.mode = 'parity' if args.workload == 'seg' else 'mx'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     run_rank(args)

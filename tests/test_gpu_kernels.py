@@ -70,6 +70,7 @@ CONV_S1 = [  # n, cin, cout, h, w
     (3, 64, 64, 16, 16), (2, 64, 64, 64, 64), (5, 128, 128, 8, 8), (2, 128, 128, 32, 32),
     (3, 256, 256, 4, 4), (2, 256, 256, 16, 16), (7, 512, 512, 2, 2), (3, 512, 512, 8, 8), (1, 64, 128, 8, 8),
     (2, 64, 64, 12, 256), (1, 64, 64, 5, 130), (1, 128, 64, 6, 200),        # maps wider than 128: the 512-pixel slab3 tiles (cfg 39)
+    (3, 64, 64, 128, 64), (1, 64, 64, 6, 64), (2, 128, 64, 8, 64),          # 64-wide maps: the row-stacked kernel (cfg 40; H % 4 != 0 falls back to slab3)
 ]
 
 
@@ -355,6 +356,44 @@ def test_pingpong_conv_equals_wide_kernel(dev, shape):
                     assert torch.equal(out, ref), (shape, planes, cfg, resid is not None, relu)
                     ran += 1
     assert ran > 0 or c < 128 or w > 33                        # (maps wider than 33: two slabs of this tile do not fit)
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64), (1, 64, 4), (5, 64, 128), (2, 128, 64)])
+def test_row_stacked_kernel_matches_slab3(dev, shape):
+    """conv3x3s1_rows_kernel (cfg 40 / 41, r04: a wave's four pixel tiles are the same 32 columns of four map rows, so one set of
+    pixel fragments serves up to three (tile, tap) steps) against conv3x3s1_slab3_kernel (cfg 38) on 64-wide maps, mode 3, with /
+    without residual and ReLU (the 96-byte line route is covered by the trunk tests).  The two accumulate the same
+    products in another order ((line, dx, dy) instead of (line, dy, dx)): fp32 sums agree to a few ulps of the largest partial sum,
+    the stored fp16 + fp6 lines therefore to one fp6 step (2^-15 of the block maximum) on rare values; pad positions stay untouched."""
+    import ctypes as C
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    lib = native.load()
+    n, c, h = shape
+    w, co = 64, 64
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(n * 11 + h)
+    x = torch.randn(n, c, h, w, generator=g).abs_()
+    r = torch.randn(n, co, h, w, generator=g)
+    wt = torch.randn(co, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5
+    wpk, bias = E.prepack_conv(wt, None, 3, dev)
+    xpf, rpf = E.pf_pack(x.to(dev), 3), E.pf_pack(r.to(dev), 3)
+    real = E.pf_pack(torch.ones(n, co, h, w).to(dev), 3).view(-1, 128)[:, :64].ne(0).any(1)
+    for resid in (None, rpf):
+        for relu in (0, 1):
+            ref = E.pf_zeros(n, co, h, w, 3, dev)
+            native.check(lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), ref.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                                    wpk.data_ptr(), bias.data_ptr(), n, h, w, c, co, 1, relu, 3, 38, st), 'cfg 38')
+            rf = E.pf_unpack(ref, n, co, h, w, 3)
+            for cfg in (40, 41):
+                out = E.pf_zeros(n, co, h, w, 3, dev)
+                native.check(lib.wsi_conv3x3_bn_act_cfg(xpf.data_ptr(), out.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                                        wpk.data_ptr(), bias.data_ptr(), n, h, w, c, co, 1, relu, 3, cfg, st), 'cfg %d' % cfg)
+                got = E.pf_unpack(out, n, co, h, w, 3)
+                err = float((got - rf).abs().max() / rf.abs().max())
+                print('rows cfg %d vs slab3: resid=%s relu=%d max rel diff %.2e, %.4f %% of the values differ' %
+                      (cfg, resid is not None, relu, err, 100.0 * float((got != rf).float().mean())))
+                assert err <= 6.2e-5, (shape, cfg, err)               # one fp6 step of a block whose maximum is the tensor's (2^-14)
+                assert not bool(out.view(-1, 128)[~real].ne(0).any()), 'kernel wrote to a pad position'
 
 
 @pytest.mark.parametrize('shape', [(8, 8192, 4096), (70, 8192, 4096), (200, 512, 128), (64, 64, 256), (65, 96, 128), (2001, 4096, 4), (33, 128, 1),

@@ -491,11 +491,12 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
 }
 
 extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_ranges, g_slab_pair;
-extern int g_l1_lines96, g_s2_nt4;
+extern int g_l1_lines96, g_s2_nt4, g_l1_rows;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
     g_ds_fold = (s2_slab & 2048) ? 0 : 1;
     g_slab_pair = (s2_slab & 4096) ? 0 : 1;
+    g_l1_rows = (s2_slab & 1024) ? 0 : 1;
     g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_s2_nt4 = (s2_slab & 32768) ? 0 : 1;
     g_xcd_ranges = (s2_slab & 256) ? 0 : (s2_slab & 512) ? 1 : 2;          // +256: off, +512: 64-channel layer only

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     constexpr int BM = WM * MT * 32;
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int RESID_NBUF = MT < 2 ? MT : 2;               // residual tiles per batch and wave (mode 3; launch_slab3 sizes the LDS)
+    constexpr bool SCHED = MINW < 3;                          // (the 168-register three-waves-per-SIMD form spills with the fences: it keeps the compiler's order)
     const int tid = threadIdx.x, lane = tid & 63;
     if (CONV_STUDY(a, CONV_ABL_DISPATCH_ONLY)) return;         // study builds: dispatch cost only
     WSTAMP(const unsigned long long st_begin = __builtin_readcyclecounter(); unsigned long long st_pro = 0, st_line = 0, st_tap = 0, st_a = 0;)
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
                     if (mt + 1 < MT) xload_m(xf[(k + 1) & 1], xoff[mt + 1] + toff, mt + 1);
                     else if (t < 8) xload_m(xf[(k + 1) & 1], xoff[0] + toff_next, 0);
                 }
+                // r04: without this fence hipcc sinks every fragment read next to its MFMA (plain memory fences do not order MFMAs:
+                // the r03 build of the layer-1 configuration held 76 `ds_read; s_waitcnt lgkmcnt(0); v_mfma` triples per line)
+                if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
                 const bf16x8(&w)[4] = wbuf[t % 3];
                 const bf16x8(&x)[4] = xf[k & 1];
                 if constexpr (ABL & 8) {
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
 #pragma unroll
                     for (int f = 0; f < 4; ++f) acc[0][mt] = mfma_bf16(w[f], x[f], acc[0][mt]);
                 }
+                if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -370,6 +375,175 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
 
 
 // --------------------------------------------------------------------------------------------
+// Row-stacked slab kernel (r04; mode 3, 64-wide maps: the trunk's 64-channel layer 1 at 256 x 256 patches).
+// Same slab, same weight path (buffer loads into a register ring), same tail as conv3x3s1_slab3_kernel<4, 2, 2, 3, ..>, but a
+// wave's four pixel tiles are the SAME 32 columns of four consecutive map rows instead of 128 consecutive pixels.  In the
+// padded-flat layout the next map row is exactly P pixels further, so tap (dy, dx) of tile row mt reads the pixel fragments of
+// slab row j = mt + dy at column shift dx: the fragment set (j, dx) serves up to three (tile, tap) steps.  Loop order per
+// 32-channel line: dx outer, slab row j = 0..5, steps (mt, dy = j - mt) inner -
+//   * 18 fragment sets (72 ds_read_b128) per line and wave instead of 36 (144): the r03 counters showed this kernel latency-bound
+//     with nothing saturated (matrix pipe 34 %, LDS 27 %, waves waiting 45 % of their life), each step waiting for its own
+//     four reads; now a set is requested while the previous one feeds up to nine MFMAs;
+//   * half the LDS address arithmetic (one swizzled base per set);
+//   * the three taps of a column (dy = 0..2 at one dx) sit in the three slots of the weight ring; slot dy is refilled with the
+//     next column's tap right after its last use (rows 3, 4, 5), two to three steps ahead of its first use.
+// Accumulation order per output is (line, dx, dy) instead of the (line, dy, dx) of every other stride-1 kernel: the results differ
+// from theirs in the last bits of the fp32 sums (same products, same precision); tests compare this kernel with the fp32
+// reference like the others, and with conv3x3s1_slab3_kernel to a few ulps.
+// NCT: input lines known at compile time (2 = the 64-channel layer 1: the line loop unrolls), 0 = any
+template <int MINW, int NCT = 0>
+__global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, WN = 2, BM = 256, NTHREADS = 256, RESID_NBUF = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    WSTAMP(const unsigned long long st_begin = __builtin_readcyclecounter(); unsigned long long st_pro = 0, st_line = 0, st_tap = 0, st_a = 0;)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;                 // wm: column half of the 64-wide map, wn: channel tile
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblocks = a.go.C / (WN * 32);
+    int nb = blockIdx.x % nblocks, mtile = blockIdx.x / nblocks;
+    if (a.flags & CONV_XCD_RANGES) {                          // XCD-contiguous tile ranges (see conv3x3s1_slab3_kernel)
+        const int chunk = gridDim.x >> 3, lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        nb = lin % nblocks;
+        mtile = lin / nblocks;
+        if (mtile >= (a.gi.N * a.gi.H * a.gi.W) / BM) return;
+    }
+    const int P = a.gi.P;                                     // 65
+    const int ntile = nb * WN + wn;
+    const int NC = NCT ? NCT : a.gi.C / 32;
+    const bool in96 = a.flags & CONV_IN96;
+    const size_t in_pixstride = (size_t)a.gi.C * (in96 ? 3 : 4);
+    const int in_line = in96 ? 96 : 128;
+    // tile = four whole rows of one image (the launcher checks W == 64, H % 4 == 0)
+    const int p0 = pf_pos_of_index(a.gi, mtile * BM);         // first pixel of the tile's first row
+    const int slab0 = p0 - P - 1;
+    const int npieces = (5 * P + 66) * 8;                     // rows -1 .. 4 of the tile: p0 + 3P + 63 + P + 1 - slab0 + 1 pixels
+    const int xoff0 = wm * 32 + l31;                          // slab-local pixel of tap (0, 0) of tile row 0
+    const size_t slab_byte0 = (size_t)slab0 * in_pixstride;
+    const size_t in_bytes = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * in_pixstride;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.in + slab_byte0), 0, (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000);
+    int xvoff;
+    bool xact = true;                                         // 96-byte lines: the lanes of the two hi6 slots fetch nothing
+    {
+        const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+        xvoff = Pl * (int)in_pixstride + (in96 ? mx96_piece(sl) : sl) * 16;
+        if (in96) xact = mx96_stored(sl);
+    }
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
+    const int wvoff = lane * 16;
+
+    f32x16 acc[1][MT];
+    auto wload = [&](bf16x8(&w)[4], int soff) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)                           // fragment offset in the SCALAR operand: one address VGPR instead of four
+            w[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, soff + f * 1024, 0));
+    };
+    auto xload = [&](bf16x8(&x)[4], int Pl) {
+        asm volatile("" : "+v"(Pl));                          // opaque: each set's address arithmetic stays at the set (no hoisting, no spills)
+        const int base = lds_xbase(Pl, h);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(smem + (base ^ (f << 5)));
+    };
+
+    bf16x8 wbuf[3][4], xf[2][4];
+    // packed weights: tap (dy, dx) of line c at ((c * 9) + dy * 3 + dx) * 4096
+    WSTAMP(const unsigned long long st_setup = __builtin_readcyclecounter();)
+#pragma unroll NCT ? NCT : 1
+    for (int c = 0; c < (NCT ? NCT : NC); ++c) {
+        WSTAMP(st_a = __builtin_readcyclecounter();)
+        if (c) __syncthreads();
+        for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
+            if (xact) dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a; st_a = __builtin_readcyclecounter();)
+        if (in96) {                                           // the slab has landed: rebuild its hi6 plane in place
+            mx96_rebuild_hi6(smem, npieces >> 3, tid, NTHREADS);
+            __syncthreads();
+        }
+        WSTAMP(st_tap += __builtin_readcyclecounter() - st_a;)
+        int Pc = P;                                           // opaque per line (see conv3x3s1_slab3_kernel)
+        asm volatile("" : "+s"(Pc));
+        const int sline = c * 9 * 4096;
+        // the line's first column of weights is requested HERE, after the hi6 rebuild pass: fetched across the slab wait it would
+        // be 48 more live registers beside the rebuild's ~45 temporaries and the 64 accumulators (168 = three waves per SIMD)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) wload(wbuf[dy], sline + (dy * 3) * 4096);
+        if (c == 0) acc_init_bias<MT>(acc[0], a.bias, ntile, lane);
+        xload(xf[0], xoff0);                                  // set (dx = 0, j = 0)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int k = dx * 6 + j;
+                // the NEXT set's four reads are in flight while this set's steps multiply: hipcc's scheduler otherwise moves the
+                // MFMAs (no memory operands) up across plain fences and waits for every set right after requesting it
+                if (j < 5) xload(xf[(k + 1) & 1], xoff0 + (j + 1) * Pc + dx);
+                else if (dx < 2) xload(xf[(k + 1) & 1], xoff0 + dx + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int dy = j - mt;
+                    if (dy >= 0 && dy < 3) acc[0][mt] = mfma_mx6(acc[0][mt], wbuf[dy], xf[k & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // slot j - 3 has seen its last step of this column: refill it with the next column's tap (next line's first column
+                // after dx = 2; nothing after the last line)
+                if (j >= 3 && dx < 2) {
+                    wload(wbuf[j - 3], sline + ((j - 3) * 3 + dx + 1) * 4096);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    WSTAMP(const unsigned long long st_loop_end = __builtin_readcyclecounter();)
+    int qs[MT];                                               // (computed here: four registers less across the main loop)
+    bool valid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        qs[mt] = p0 + mt * P + wm * 32 + l31;
+        valid[mt] = true;
+    }
+    if (a.resid) __syncthreads();                             // every wave is done reading pixel fragments: slab memory becomes
+    conv_tail_mx<1, MT, RESID_NBUF>(a, acc, qs, valid, ntile, lane, smem + wave * (RESID_NBUF * 4096), slab0);   // the waves' residual staging
+#ifdef WSI_STUDY
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && (blockIdx.x & 63) == 0) {
+        const unsigned long long st_end = __builtin_readcyclecounter();
+        atomicAdd(&g_wide_stamps[0], 1ull);
+        atomicAdd(&g_wide_stamps[1], st_end - st_begin);
+        atomicAdd(&g_wide_stamps[2], st_setup - st_begin);
+        atomicAdd(&g_wide_stamps[3], st_pro);
+        atomicAdd(&g_wide_stamps[4], st_line);
+        atomicAdd(&g_wide_stamps[5], st_tap);
+        atomicAdd(&g_wide_stamps[6], st_end - st_loop_end);
+    }
+#endif
+}
+
+template <int MINW>
+static int launch_rows(const ConvArgs& a, hipStream_t st) {
+    const bool nc2 = a.gi.C == 64;
+    constexpr int BM = 256, NTHREADS = 256;
+    if (a.go.C % 64 || a.gi.C % 32 || a.gi.W != 64 || a.gi.H % 4 || a.in2) return WSI_EINVAL;
+    const int nblocks = a.go.C / 64;
+    const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
+    const int mtiles = (int)(R / BM);                        // whole tiles: H % 4 == 0
+    const int npix = 5 * a.gi.P + 66;
+    size_t lds = (size_t)((npix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    if (lds < (size_t)4 * 8192) lds = (size_t)4 * 8192;      // residual staging of the tail (8 KB per wave)
+    auto k = nc2 ? conv3x3s1_rows_kernel<MINW, 2> : conv3x3s1_rows_kernel<MINW, 0>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return WSI_EINVAL;
+    const int grid = (a.flags & CONV_XCD_RANGES) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+
+// --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
 // 128 accumulator registers), so a pixel-fragment set read from LDS feeds SIX MFMAs instead of three and the
 // operand-load instructions per MFMA drop from 1.67 to 1.0 (the r01 ablations showed the slab3 loop is bound by
@@ -403,8 +577,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     const int P = a.gi.P;
     const int NC = a.gi.C / PFmt<PLANES>::CPL;
     const size_t in_pixstride = (size_t)a.gi.C * PFmt<PLANES>::BPC;
-    int xoff[MT], qs[MT];
-    bool valid[MT];
+    int xoff[MT];                                             // slab-local pixel of tap (0, 0) per tile row; the PF position is
+    bool valid[MT];                                           // xoff + slab0 + P + 1 (rebuilt after the main loop: four registers less in it)
     int slab0, npieces;
     const int lpix = a.gi.W < 32 ? dense_lane_pixel(l31) : l31;      // bank-conflict-free lane order on narrow maps (conv_dev.h)
     {
@@ -417,8 +591,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         for (int mt = 0; mt < MT; ++mt) {
             const int i = i0 + wm * MT * 32 + mt * 32 + lpix;
             valid[mt] = i < R;
-            qs[mt] = pos(valid[mt] ? i : i1);
-            xoff[mt] = qs[mt] - slab0 - (P + 1);
+            xoff[mt] = pos(valid[mt] ? i : i1) - slab0 - (P + 1);
         }
     }
     // slab DMA by buffer addressing (see conv3x3s1_slab3_kernel): one per-lane byte offset, scalar offsets per line / round
@@ -432,14 +605,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
         xvoff = Pl * (int)in_pixstride + sl * 16;
     }
-    const char* wsrc = (const char*)a.wpk + (size_t)(nb * NTILES) * NC * 9 * 4096 + (size_t)(tid & 255) * 16;
-    // weights of (line c, tap t) for the workgroup's NTILES channel tiles -> buffer wb: 256 pieces of 16 B per tile
-    auto wdma = [&](int c, int t, char* wb) {
+    // weights of (line c, tap t) for the workgroup's NTILES channel tiles -> buffer wb: 256 pieces of 16 B per tile.  Main-loop DMA
+    // (weights one tap ahead, slab) goes through dma16_buf_asm: a pending LDS-DMA *builtin* makes hipcc wait lgkmcnt(0) before
+    // every MFMA group, i.e. for the pixel fragments it has just requested for the NEXT group (conv_dev.h)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)(nb * NTILES) * NC * 9 * 4096), 0, NTILES * NC * 9 * 4096, 0x00020000);
+    const int wvoff = (tid & 255) * 16;
+    const unsigned wl_addr = lds_addr_of(wl), xl_addr = lds_addr_of(xl);
+    auto wdma = [&](int c, int t, int wboff) {
 #pragma unroll
         for (int p0 = 0; p0 < NTILES * 256; p0 += NTHREADS) {
             static_assert((NTILES * 256) % NTHREADS == 0, "whole DMA rounds");
             const int pw = p0 + wave * 64;                   // first piece of this wave's 1 KB chunk (wave-uniform)
-            dma16(wsrc + ((size_t)((pw >> 8) * NC + c) * 9 + t) * 4096, wb + pw * 16);   // piece (tid & 255) of tile pw >> 8
+            dma16_buf_asm(wrs, wl_addr + wboff + pw * 16, wvoff, (((pw >> 8) * NC + c) * 9 + t) * 4096);   // piece (tid & 255) of tile pw >> 8
         }
     };
 
@@ -473,8 +651,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         WSTAMP(st_a = __builtin_readcyclecounter();)
         if (c) __syncthreads();                               // slab and weight buffers are free again
         for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-            dma16_buf(xrs, xl + (size_t)i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
-        wdma(c, 0, wl + kpar * WB);
+            dma16_buf_asm(xrs, xl_addr + i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
+        wdma(c, 0, kpar * WB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a;)
@@ -485,7 +663,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const char* wb = wl + kpar * WB;
-            if (t < 8) wdma(c, t + 1, wl + (kpar ^ 1) * WB);
+            if (t < 8) wdma(c, t + 1, (kpar ^ 1) * WB);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wread(wf[nt], wb, nt);
             const int toff = (t / 3) * Pc + (t % 3);
@@ -514,6 +692,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         }
     }
     WSTAMP(const unsigned long long st_loop_end = __builtin_readcyclecounter();)
+    int qs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) qs[mt] = xoff[mt] + slab0 + (P + 1);
     if constexpr (PLANES == 3) {
         if (a.in2) {
             // Extra K segment (common.h ConvArgs.in2): the strided block's 1x1 downsample of the block input, one centre tap per
@@ -870,8 +1051,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
     auto wdma = [&](int c, int t, char* wb) {
 #pragma unroll
         for (int j = 0; j < NTILES; ++j) {
-            if (t < 9) dma16_buf(wrs, wb + j * 4096 + (wave - 4) * 1024, wvoff, ((j * NC + c) * 9 + t) * 4096 + (wave - 4) * 1024);
-            else dma16_buf(wrd, wb + j * 4096 + (wave - 4) * 1024, wvoff, (j * NC + c) * 4096 + (wave - 4) * 1024);
+            // (asm DMA: a pending LDS-DMA builtin turns every counted LDS wait of the loop into lgkmcnt(0), conv_dev.h)
+            if (t < 9) dma16_buf_asm(wrs, lds_addr_of(wb) + j * 4096 + (wave - 4) * 1024, wvoff, ((j * NC + c) * 9 + t) * 4096 + (wave - 4) * 1024);
+            else dma16_buf_asm(wrd, lds_addr_of(wb) + j * 4096 + (wave - 4) * 1024, wvoff, (j * NC + c) * 4096 + (wave - 4) * 1024);
         }
     };
     // pixels of (line c, phase ph) -> buffer xb (waves 0..3)
@@ -882,7 +1064,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         for (int i0 = wave * 64; i0 < npieces; i0 += 256) {
             const int i = i0 + lane;
             const int Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
-            dma16(src + (size_t)Pl * in_pixstride + sl * 16, xb + (size_t)i0 * 16);
+            dma16_asm(src + (size_t)Pl * in_pixstride + sl * 16, lds_addr_of(xb) + i0 * 16);
         }
     };
     auto wread = [&](bf16x8(&w)[NT][4], const char* wb) {
@@ -949,25 +1131,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
                 for (int k = 0; k < ulen; ++k) {
                     const int g = c * SPL + j0 + k;
                     const int t = STEP_TAP[j0 + k];
-                    bf16x8 wf[NT][4], xf[MT][4];
+                    constexpr bool PREF = NT == 2 && !DS;      // (with four channel tiles, or the second accumulator set, the fenced order needs > 256 registers)
+                    bf16x8 wf[NT][4], xf[PREF ? 2 : MT][4];
                     wread(wf, wl + (g & (NWB - 1)) * WBUF);
                     const int sh = (t < 9 && t % 3 == 2 ? 1 : 0) + (t < 9 && t / 3 == 2 ? P : 0);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
+                    auto xload = [&](bf16x8(&x)[4], int mt) {
                         int ql = qs[mt] - q0;
                         asm volatile("" : "+v"(ql));           // opaque: the address arithmetic of every (line, step) is done HERE (hoisted
                         const int Pl = ql + sh;                // out of the line loop it costs ~70 registers and spills into the loop)
                         const int base = lds_xbase(Pl, h);
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) xf[mt][f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
-                    }
+                        for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
+                    };
+                    if constexpr (PREF) {
+                        // r04: the pixel fragments of tile mt + 1 are requested before the MFMAs of tile mt and stay in flight under
+                        // them (r03 read all four tiles' fragments, waited for everything, then multiplied)
+                        xload(xf[0], 0);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (mt + 1 < MT) xload(xf[(mt + 1) & 1], mt + 1);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            if constexpr (DS) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
-                            else mfma_step<PLANES>(acc[nt][mt], wf[nt], xf[mt]);
+                            for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(acc[nt][mt], wf[nt], xf[mt & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) xload(xf[mt], mt);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                if constexpr (DS) mfma_step<PLANES>(t == 9 ? accd[nt][mt] : acc[nt][mt], wf[nt], xf[mt]);
+                                else mfma_step<PLANES>(acc[nt][mt], wf[nt], xf[mt]);
+                            }
+                    }
                 }
                 // end of the unit: the weight waves wait for the next unit's stages, the pixel waves (at an item's last unit)
                 // for the next item's pixels
@@ -1020,6 +1218,7 @@ static int launch_s2wide(const ConvArgs& a, hipStream_t st) {
 }
 
 int g_s2_ablate = 0;
+int g_l1_rows = 1;                                       // A/B (wsi_conv_set_mode +1024 off): row-stacked layer-1 kernel (cfg 40) instead of slab3 (cfg 38)
 int g_slab_pair = 1;                                     // A/B (wsi_conv_set_mode +4096 off): paired-tile LDS addressing of the layer-1 kernel
 int g_xcd_ranges = 2;                                    // XCD-contiguous tile ranges: 1 = the 64-channel layer only, 2 = every stride-1 layer (r01: ~-1 % overall)
 int g_xcd_order = 0;                                     // 1: CONV_XCD_ORDER for multi-channel-block launches
@@ -1090,14 +1289,17 @@ int wsi_pp_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);    
 int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t st) {
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
-    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 40) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 90)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
-    if ((a.flags & CONV_IN96) && !((cfg >= 20 && cfg < 40) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // 96-byte input lines: slab3 kernels only
+    if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 42) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 90)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
+    if ((a.flags & CONV_IN96) && !((cfg >= 20 && cfg < 42) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // 96-byte input lines: slab3 / row-stacked kernels only
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
     if (cfg >= 70 && cfg < 90) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
     // cfg 90: 512 px x 32 couts (8 x 1 waves, two pixel tiles each) for 32-channel outputs (U-Net decoder levels 4-5)
     if (cfg == 90) return planes == 3 ? launch_slab3<2, 8, 1, 3, 1, true>(a, st) : planes == 2 ? launch_slab3<2, 8, 1, 2, 1, true>(a, st) : WSI_EINVAL;
     // cfg 91: 256 px x 32 couts, the fallback where a 512-pixel tile's slab exceeds the LDS (tiles straddling two images of a wide map)
     if (cfg == 91) return planes == 3 ? launch_slab3<2, 4, 1, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<2, 4, 1, 2, 2, true>(a, st) : WSI_EINVAL;
+    // cfg 40 / 41: row-stacked layer-1 kernel (mode 3, 64-wide maps), three / two workgroups per CU
+    if (cfg == 40) return planes == 3 ? launch_rows<3>(a, st) : WSI_EINVAL;
+    if (cfg == 41) return planes == 3 ? launch_rows<2>(a, st) : WSI_EINVAL;
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
 #ifdef WSI_STUDY
     if (cfg == 61 && planes == 3) return launch_wide<3, 2, 32>(a, st);               // ablation: no pixel-fragment reads
@@ -1155,6 +1357,7 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     if (planes == 2 && a.go.C == 128 && a.gi.W > 8 && g_wide_min_c <= 128) return 30;
     if (a.go.C % 128 == 0 && a.go.C >= g_wide_min_c && !(planes == 1 && a.gi.W > 33)) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
+    if (a.go.C % 128 != 0 && planes == 3 && !fallback && g_l1_rows && a.gi.W == 64 && a.gi.H % 4 == 0 && !a.in2) return 40;   // r04: row-stacked tiles (A/B: wsi_conv_set_mode +1024 off)
     if (a.go.C % 128 != 0 && planes == 3 && !fallback) return 38;         // r03 tune, layer 1: 1.416 / 1.619 ms vs 1.435 / 1.666 (cfg 31), n = 2000
     return a.go.C % 128 == 0 ? 30 : 31;
 }

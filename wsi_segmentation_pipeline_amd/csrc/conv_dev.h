@@ -21,6 +21,25 @@ static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// The same transfer issued from inline asm, for DMA that stays in flight WHILE the wave reads other parts of the LDS (weight stages
+// requested one tap ahead, slabs one line ahead).  r04 finding: with an LDS-DMA builtin pending, hipcc's wait-count pass stops
+// counting LDS reads - every `s_waitcnt lgkmcnt(N)` in the loop becomes `lgkmcnt(0)`, so pixel fragments requested one step ahead
+// are awaited right after their request (the wide kernel's main loop held 6 such full waits per tap where the same loop without
+// the pending DMA has lgkmcnt(4) / (7) / (11)).  An asm DMA is invisible to that pass: the reads keep their counted waits, and the
+// DMA is awaited where the kernel says so (`s_waitcnt vmcnt(0)` + barrier before the stage is read - the kernels did that
+// explicitly already).  Any vmcnt wait the compiler computes for its own loads only gets more conservative by unknown younger
+// requests (in-order completion), never unsafe.  `lds` = byte address of the wave's 1 KiB destination (wave-uniform).
+static __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+static __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds) {       // per-lane 64-bit source address
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds), "v"(gsrc) : "memory");
+}
+static __device__ __forceinline__ void dma16_buf_asm(__amdgpu_buffer_rsrc_t rs, unsigned lds, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 // Residual tile (32 pixels x one 128-byte line) -> 4 KB of LDS at dst by LDS-DMA, eight lanes per line: piece
 // i = j*64 + lane is slot (i & 7) of tile pixel i >> 3, stored swizzled like the pixel slabs (source-side XOR).  q = this
 // lane's own pixel (PF index; lanes p and p+32 hold the same); the owning lanes hand it out by ds_bpermute.
@@ -193,7 +212,10 @@ static __device__ __forceinline__ f32x16 mfma_mx6(f32x16 d, const bf16x8 (&w)[4]
     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, x[1]), d, 0, 0, 0);
     const i32x4 wq = __builtin_bit_cast(i32x4, w[2]), wr = __builtin_bit_cast(i32x4, w[3]);
     const i32x4 xq = __builtin_bit_cast(i32x4, x[2]), xr = __builtin_bit_cast(i32x4, x[3]);
-    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], wr[0], wr[1], 0, 0}, xa = {xq[0], xq[1], xq[2], xq[3], xr[0], xr[1], 0, 0};
+    // fp6 operands are 192 bits: the instruction reads registers 0-5 of each operand tuple (the backend selects the 6-register
+    // form for cbsz = blgp = 2), so the tuple is simply the two 16-byte fragments back to back - no zero filling, hence no copies
+    // of a fragment into a fresh 8-register tuple (r04: those copies cost the row-stacked kernel 40 registers)
+    const i32x8 wa = {wq[0], wq[1], wq[2], wq[3], wr[0], wr[1], wr[2], wr[3]}, xa = {xq[0], xq[1], xq[2], xq[3], xr[0], xr[1], xr[2], xr[3]};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, d, 2, 2, 0, wr[2], 0, xr[2]);
 }
 

@@ -185,6 +185,11 @@ class TrunkEngine:
         if ent is not None:                                 # the library forgets the address before the allocator can reuse it
             self.lib.wsi_trunk_workspace_release(_ptr(ent[0]))
 
+    def release_workspaces(self):
+        """Free every planned workspace (they are re-planned on the next forward)."""
+        for key in list(self._ws):
+            self._drop_workspace(key)
+
     def __del__(self):
         try:
             for key in list(getattr(self, '_ws', {})):
