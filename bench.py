@@ -370,23 +370,30 @@ def run_rank(args):
         lines96 = planes == MX and not (args.s2 >= 0 and args.s2 & 16384)
         alg = (7.75 / 4 if lines96 else 2.5) * tensor
         gbs = alg / (l1['avg_ms'] * 1e-3) / 1e9
-        roofline_l1 = {'kernel': 'conv3x3s1_slab3_kernel<4,2,2,...> (4 launches per batch: the 64-channel layer 1)', 'bound': 'hbm',
+        l1_names = ('conv3x3s1_rows_kernel', 'conv3x3s1_slab3_kernel<4, 2, 2')
+        l1_sel = [v for k_, v in tj['kernels'].items() if any(x in k_ for x in l1_names)] if tj else []
+        sc = eff_batch / float(tj.get('batch', 1000)) if tj else 0.0
+        traffic_l1 = None
+        if not lines96:
+            traffic_l1 = pmc_bytes(l1_names, eff_batch)
+        elif l1_sel and all('hbm_bytes_per_launch_calibrated96' in v for v in l1_sel):
+            # 96-byte lines: FETCH_SIZE calibrated per access pattern (slab x0.972, residual tiles x0.5: tools/probes/fetch_calib96,
+            # tools/traffic_json.py), WRITE_SIZE exact
+            nl = sum(v['launches'] for v in l1_sel)
+            traffic_l1 = round(sum(v['hbm_bytes_per_launch_calibrated96'] * v['launches'] for v in l1_sel) / nl * sc)
+        roofline_l1 = {'kernel': 'conv3x3s1_rows_kernel (r04; 4 launches per batch: the 64-channel layer 1 on 64-wide maps)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-                       'traffic': None if lines96 else pmc_bytes('conv3x3s1_slab3_kernel<4, 2, 2', eff_batch),
+                       'traffic': traffic_l1,
                        'algorithmic_bytes_per_launch': round(alg), 'line_bytes': 96 if lines96 else 128,
                        'avg_launch_ms': round(l1['avg_ms'], 4), 'tflops': round(l1['tflops'], 2)}
-        if lines96 and tj:
-            # FETCH_SIZE is uncalibrated for reads of 96-byte lines (MI355X_MICROARCH.md: the x2 rule holds for wide coalesced reads;
-            # tools/probes/fetch_calib96 counts x1.03 when a pixel's two lines are fetched back to back, sector arithmetic for the
-            # kernel's own order gives ~x1.2): no `traffic` figure, the exact WRITE_SIZE and the raw FETCH_SIZE instead
-            sel = [v for k_, v in tj['kernels'].items() if 'conv3x3s1_slab3_kernel<4, 2, 2' in k_]
-            if sel:
-                nl = sum(v['launches'] for v in sel)
-                sc = eff_batch / float(tj.get('batch', 1000))
-                roofline_l1['traffic_parts'] = {
-                    'write_bytes_per_launch': round(sum(v['write_bytes_per_launch'] * v['launches'] for v in sel) / nl * sc),
-                    'fetch_size_raw_bytes_per_launch': round(sum(v['read_bytes_per_launch'] * v['launches'] for v in sel) / nl * sc / 2),
-                    'note': 'FETCH_SIZE uncalibrated for 96-byte-line reads (x1.03 .. x2): no total; algorithmic reads are 59 % of the algorithmic bytes'}
+        if lines96 and l1_sel:
+            nl = sum(v['launches'] for v in l1_sel)
+            roofline_l1['traffic_parts'] = {
+                'write_bytes_per_launch': round(sum(v['write_bytes_per_launch'] * v['launches'] for v in l1_sel) / nl * sc),
+                'fetch_size_raw_bytes_per_launch': round(sum(v['read_bytes_per_launch'] * v['launches'] for v in l1_sel) / nl * sc / 2),
+                'note': ('FETCH_SIZE of 96-byte-line reads is calibrated per pattern (tools/traffic_json.py): slab reads are tallied at x0.972 of '
+                         'their bytes, the residual tile reads at x0.5') if traffic_l1 else
+                        'FETCH_SIZE uncalibrated for 96-byte-line reads (x1.03 .. x2): no total; algorithmic reads are 59 % of the algorithmic bytes'}
 
     # the same dominant kernel in single-pass bf16 (the literal dtype of BASELINE configs[1]; logit error ~2e-2, outside the
     # contract, so never the headline): one profiled pass on rank 0, outside the timed region

@@ -34,6 +34,30 @@ __global__ __launch_bounds__(256) void k(const char* in, long long npix, unsigne
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// The tail's residual pattern (conv_dev.h resid_tile_dma_buf96): a wave fetches 32-pixel tiles of ONE 96-byte line - four DMA
+// instructions per tile, eight lanes per pixel (slots 5 / 7 idle), its partner wave the same pixels' other line at about the same
+// time - 256 pixels per workgroup (the layer-1 kernels' tile), every pixel-line once.
+__global__ __launch_bounds__(256) void kres(const char* in, long long npix, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long p0 = (long long)blockIdx.x * 256;
+    if (p0 + 256 > npix) return;
+    const int pixstride = 192;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(in + p0 * pixstride), 0, 256 * pixstride, 0x00020000);
+    const int half = wave >> 1, line = wave & 1;               // waves (0,1) = pixels 0-127, (2,3) = 128-255; wave parity = line
+    unsigned acc = 0;
+    for (int t = 0; t < 4; ++t) {                              // four 32-pixel tiles per wave
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pp = 8 * j + (lane >> 3), q = half * 128 + t * 32 + pp;
+            const int sl = (lane & 7) ^ ((pp >> 1) & 7);
+            if (sl != 5 && sl != 7) dma16_buf(rs, smem + wave * 4096 + j * 1024, q * pixstride + (sl == 6 ? 5 : sl) * 16, line * 96);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc += *(const unsigned*)(smem + wave * 4096 + lane * 16);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 int main(int argc, char** argv) {
     const long long npix = (argc > 1 ? atoll(argv[1]) : 4096) * 4096ll;      // default 16 Mi pixels: 4 GiB / 3 GiB
     char* in; unsigned* sink;
@@ -42,7 +66,10 @@ int main(int argc, char** argv) {
     const int grid = (int)(npix / 384);                         // whole workgroups only: nothing is read past the allocation
     hipLaunchKernelGGL(k<false>, dim3(grid), dim3(256), 384 * 128, 0, in, npix, sink);
     hipLaunchKernelGGL(k<true>, dim3(grid), dim3(256), 384 * 128, 0, in, npix, sink);
+    const int gres = (int)(npix / 256);
+    hipLaunchKernelGGL(kres, dim3(gres), dim3(256), 4 * 4096, 0, in, npix, sink);
     hipDeviceSynchronize();
-    printf("needed bytes: k<false> (128-byte lines) %lld, k<true> (96-byte lines) %lld\n", (long long)grid * 384 * 256, (long long)grid * 384 * 192);
+    printf("needed bytes: k<false> (128-byte lines) %lld, k<true> (96-byte lines) %lld, kres (96-byte lines, residual tile pattern) %lld\n",
+           (long long)grid * 384 * 256, (long long)grid * 384 * 192, (long long)gres * 256 * 192);
     return 0;
 }

@@ -38,6 +38,23 @@ for which in ('fetch', 'write'):
             name = r['Kernel_Name'].split('(')[0].replace('void ', '')
             if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
                 acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
+# Layer-1 kernels read 96-byte lines (r03+), for which FETCH_SIZE needs its own factors (tools/probes/fetch_calib96 under
+# --pmc FETCH_SIZE, profiles/r04_fetch_calib96.txt): the slab pattern is tallied at CAL96_SLAB of its bytes, the tail's residual
+# tile pattern at CAL96_RESID.  Launches alternate without / with a residual, so the per-dispatch counters fall into two
+# clusters: reads(no residual) = A / CAL96_SLAB, reads(residual) = A / CAL96_SLAB + (B - A) / CAL96_RESID.
+CAL96_SLAB = float(os.environ.get('WSI_CAL96_SLAB', '0.945'))
+CAL96_RESID = float(os.environ.get('WSI_CAL96_RESID', '0.5'))
+
+
+def layer1_reads(values_kib):
+    v = sorted(values_kib)
+    if len(v) < 2:
+        return None
+    lo, hi = v[:len(v) // 2], v[len(v) // 2:]
+    a, b = 1024.0 * sum(lo) / len(lo), 1024.0 * sum(hi) / len(hi)
+    return 0.5 * (a / CAL96_SLAB + a / CAL96_SLAB + max(b - a, 0.0) / CAL96_RESID), a, b
+
+
 res = {}
 for name, d in acc.items():
     if not any(k in name for k in ('conv3x3', 'stem_pool', 'conv_gather', 'avgpool', 'stitch', 'softmax')):
@@ -47,6 +64,15 @@ for name, d in acc.items():
     write = 1024.0 * sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1)
     res[name] = {'launches': n, 'read_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
                  'hbm_bytes_per_launch': fetch + write}
+    if ('rows_kernel' in name or 'slab3_kernel<4, 2, 2, 3' in name) and '--s2' not in ' '.join(sys.argv[3:]):
+        cal = layer1_reads(d['FETCH_SIZE'])
+        if cal:
+            res[name]['read_bytes_per_launch_calibrated96'] = cal[0]
+            res[name]['hbm_bytes_per_launch_calibrated96'] = cal[0] + write
+            res[name]['fetch_raw_bytes_no_residual_launches'] = cal[1]
+            res[name]['fetch_raw_bytes_residual_launches'] = cal[2]
+            res[name]['calibration'] = {'slab_pattern_factor': CAL96_SLAB, 'residual_pattern_factor': CAL96_RESID,
+                                        'source': 'tools/probes/fetch_calib96 under rocprofv3 --pmc FETCH_SIZE'}
 slab = {k: v for k, v in res.items() if 'conv3x3s1_' in k}      # slab3 + wide: all stride-1 3x3 launches
 tot_l = sum(v['launches'] for v in slab.values())
 batch, tiles, cap = launch_batch(sys.argv[3:])

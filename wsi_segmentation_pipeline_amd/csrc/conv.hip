@@ -390,8 +390,11 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
 // Accumulation order per output is (line, dx, dy) instead of the (line, dy, dx) of every other stride-1 kernel: the results differ
 // from theirs in the last bits of the fp32 sums (same products, same precision); tests compare this kernel with the fp32
 // reference like the others, and with conv3x3s1_slab3_kernel to a few ulps.
-// NCT: input lines known at compile time (2 = the 64-channel layer 1: the line loop unrolls), 0 = any
-template <int MINW, int NCT = 0>
+// NCT: input lines known at compile time (2 = the 64-channel layer 1: the line loop unrolls), 0 = any.  IN96: 96-byte input lines
+// (hi6 plane rebuilt in LDS after the slab has landed).  With 128-byte lines there is no rebuild pass whose ~45 temporaries compete
+// with the weight ring for registers, so a line's first column of weights is requested across the line boundary (during the
+// previous line's last column; line 0: before the slab DMA) instead of after the slab wait.
+template <int MINW, int NCT = 0, bool IN96 = true>
 __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 4, WN = 2, BM = 256, NTHREADS = 256, RESID_NBUF = 2;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
     const int P = a.gi.P;                                     // 65
     const int ntile = nb * WN + wn;
     const int NC = NCT ? NCT : a.gi.C / 32;
-    const bool in96 = a.flags & CONV_IN96;
+    constexpr bool in96 = IN96;
     const size_t in_pixstride = (size_t)a.gi.C * (in96 ? 3 : 4);
     const int in_line = in96 ? 96 : 128;
     // tile = four whole rows of one image (the launcher checks W == 64, H % 4 == 0)
@@ -449,6 +452,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
 
     bf16x8 wbuf[3][4], xf[2][4];
     // packed weights: tap (dy, dx) of line c at ((c * 9) + dy * 3 + dx) * 4096
+    constexpr bool XLINE = !IN96 && NCT > 0;                  // (a runtime line loop would carry the ring across its back edge: spills)
+    if constexpr (XLINE) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) wload(wbuf[dy], (dy * 3) * 4096);       // line 0's first column flies during the slab DMA
+    }
     WSTAMP(const unsigned long long st_setup = __builtin_readcyclecounter();)
 #pragma unroll NCT ? NCT : 1
     for (int c = 0; c < (NCT ? NCT : NC); ++c) {
@@ -469,8 +477,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
         const int sline = c * 9 * 4096;
         // the line's first column of weights is requested HERE, after the hi6 rebuild pass: fetched across the slab wait it would
         // be 48 more live registers beside the rebuild's ~45 temporaries and the 64 accumulators (168 = three waves per SIMD)
+        if constexpr (!XLINE) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) wload(wbuf[dy], sline + (dy * 3) * 4096);
+            for (int dy = 0; dy < 3; ++dy) wload(wbuf[dy], sline + (dy * 3) * 4096);
+        }
         if (c == 0) acc_init_bias<MT>(acc[0], a.bias, ntile, lane);
         xload(xf[0], xoff0);                                  // set (dx = 0, j = 0)
 #pragma unroll
@@ -491,8 +501,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // slot j - 3 has seen its last step of this column: refill it with the next column's tap (next line's first column
                 // after dx = 2; nothing after the last line)
-                if (j >= 3 && dx < 2) {
-                    wload(wbuf[j - 3], sline + ((j - 3) * 3 + dx + 1) * 4096);
+                if (j >= 3 && (dx < 2 || (XLINE && c + 1 < NC))) {
+                    wload(wbuf[j - 3], dx < 2 ? sline + ((j - 3) * 3 + dx + 1) * 4096 : sline + (9 + (j - 3) * 3) * 4096);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -534,7 +544,9 @@ static int launch_rows(const ConvArgs& a, hipStream_t st) {
     const int npix = 5 * a.gi.P + 66;
     size_t lds = (size_t)((npix * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (lds < (size_t)4 * 8192) lds = (size_t)4 * 8192;      // residual staging of the tail (8 KB per wave)
-    auto k = nc2 ? conv3x3s1_rows_kernel<MINW, 2> : conv3x3s1_rows_kernel<MINW, 0>;
+    const bool i96 = a.flags & CONV_IN96;
+    auto k = nc2 ? (i96 ? conv3x3s1_rows_kernel<MINW, 2, true> : conv3x3s1_rows_kernel<MINW, 2, false>)
+                 : (i96 ? conv3x3s1_rows_kernel<MINW, 0, true> : conv3x3s1_rows_kernel<MINW, 0, false>);
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return WSI_EINVAL;
     const int grid = (a.flags & CONV_XCD_RANGES) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;
@@ -1358,6 +1370,10 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     if (a.go.C % 128 == 0 && a.go.C >= g_wide_min_c && !(planes == 1 && a.gi.W > 33)) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
     if (a.go.C % 128 != 0 && planes == 3 && !fallback && g_l1_rows && a.gi.W == 64 && a.gi.H % 4 == 0 && !a.in2) return 40;   // r04: row-stacked tiles (A/B: wsi_conv_set_mode +1024 off)
+    // r04: with the scheduling fences the two-waves-per-SIMD form (cfg 31) beats the fence-less 168-register form (cfg 38) on
+    // 16 x 16 maps (cfg4's layer 1, n = 32000: 1.552 vs 1.693 ms); 64-wide maps whose height is no multiple of four keep cfg 38
+    // (1.545 vs 1.590 ms; profiles/r04_tune_slab3_fences.log)
+    if (a.go.C % 128 != 0 && planes == 3 && !fallback && a.gi.W != 64) return 31;
     if (a.go.C % 128 != 0 && planes == 3 && !fallback) return 38;         // r03 tune, layer 1: 1.416 / 1.619 ms vs 1.435 / 1.666 (cfg 31), n = 2000
     return a.go.C % 128 == 0 ? 30 : 31;
 }

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
 #pragma unroll
     for (int r = 0; r < 16; ++r) carry[r] = 0.f;
     const bool col_ok = (c0 + l31) >= 0 && (c0 + l31) < Wc && (even || l31 < 31);
+    const float col_ub = col_ok ? (OUT == 3 ? 65504.f : 3.4028234e38f) : 0.f;
     const int lc = (even || l31 < 31) ? l31 : 30;                       // odd layout: lane 31 is idle, keep its reads inside the row
     const bool o96 = OUT == 3 && A.out96;
     const size_t pixstride = (size_t)64 * (o96 ? 3 : PFmt<OUT>::BPC);
@@ -445,8 +446,10 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 const float m = fmaxf(fmaxf(carry[r], c0), c1);
                 carry[r] = c1;
                 const int ch = wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                const float t = fmaxf(__builtin_fmaf(m, sb_lds[ch], sb_lds[64 + ch]), 0.f);   // explicit FMA (the build runs with -ffp-contract=off)
-                v[r] = col_ok ? t : 0.f;                                // columns outside the map are the pool's padding
+                // ReLU, the column mask (columns outside the map are the pool's padding: 0) and - mode 3 - the fp16-range clamp of
+                // the line encode in ONE v_med3_f32: clamp(x, 0, ub) with ub = 0 on masked columns (r03: v_max + v_cndmask here and
+                // a v_min per value before the encode; min commutes with the horizontal max below, so the bits are the same)
+                v[r] = __builtin_amdgcn_fmed3f(__builtin_fmaf(m, sb_lds[ch], sb_lds[64 + ch]), 0.f, col_ub);   // explicit FMA (-ffp-contract=off)
             }
             if (py < 0) {                                               // (uniform; first step of the first segment only)
 #pragma unroll
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 float mh = 0.f, ml = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float v0 = fminf(v[r], 65504.f), v1 = fminf(v[r + 1], 65504.f);
+                    const float v0 = U8X ? v[r] : fminf(v[r], 65504.f), v1 = U8X ? v[r + 1] : fminf(v[r + 1], 65504.f);   // (integer path: clamped above)
                     const f16x2 hh = __builtin_convertvector(f32x2{v0, v1}, f16x2);
                     hv[r >> 3][r & 7] = hh[0];
                     hv[r >> 3][(r & 7) + 1] = hh[1];
