@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSI_HIP_ABI_VERSION 3
+#define WSI_HIP_ABI_VERSION 4
 int wsi_hip_abi_version(void);
 
 /* ---- padded-flat layout helpers (host) -------------------------------------------------------

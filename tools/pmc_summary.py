@@ -27,5 +27,8 @@ for key in sorted(acc):
             derived['LDS bank-conflict cycles / LDS active cycles'] = g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE')
         if g('SQ_WAVE_CYCLES') and g('SQ_WAIT_ANY') is not None:
             derived['share of wave lifetime waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES)'] = g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES')
+        if g('GRBM_GUI_ACTIVE'):
+            # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs' matrix-pipe cycles
+            derived['matrix pipe busy share (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / (g('GRBM_GUI_ACTIVE') * 128.0)
         for k, v in derived.items():
-            print('    -> %-60s %.3f' % (k, v))
+            print('    -> %-96s %.3f' % (k, v))

@@ -133,7 +133,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 3                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
+ABI_VERSION = 4                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
 
 
 def load():
