@@ -81,9 +81,9 @@ class ResNet(nn.Module):
             for mod in self.modules():
                 if isinstance(mod, BasicBlock):
                     nn.init.zeros_(mod.bn2.weight)
-        # 'auto' (default: mx unless a two-mode probe of the first batch shows its logits more than 4e-4 from parity mode:
-        # engine.AutoTrunkEngine), 'parity' (bf16x2 split, 3 MFMA passes, logit error ~3e-5), 'mx' (fp16 + MX-fp4 cross
-        # terms, ~3e-4 at |logit| <= 5, grows with the logit scale, ~1.35x faster) or 'speed' (single bf16, ~2e-2, outside
+        # 'auto' (default: mx unless a stratified two-mode probe of the batch / slide shows its logits more than 5e-4 from parity
+        # mode: engine.AutoTrunkEngine), 'parity' (bf16x2 split, 3 MFMA passes, logit error ~3e-5), 'mx' (fp16 + MX-fp6 cross
+        # terms, <= 5.4e-4 up to |logit| = 16, grows with the logit scale, ~1.5x faster) or 'speed' (single bf16, ~2e-2, outside
         # the 1e-3 contract)
         self.precision = precision
         self._engine = None
