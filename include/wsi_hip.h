@@ -94,6 +94,14 @@ int wsi_conv1x1_bn(const void* in_pf, void* out_pf, const void* wpk, const float
 /* The two stride-2 convs of a downsampling BasicBlock in one pass over the input
  * (resnets_shift.py:41 conv1 with stride 2 + ReLU, and :173-177 the 1x1 stride-2 downsample, no ReLU):
  * out_conv_pf = relu(bn1(conv3x3_s2(x))), out_ds_pf = bn_d(conv1x1_s2(x)).  cout % 128 == 0. */
+/* The first conv of a U-Net decoder block with its input assembly fused in (r04): out = act(bn(conv3x3(cat(up2(up_pf), skip_pf)))),
+ * i.e. segmentation_models_pytorch's DecoderBlock `x = F.interpolate(x, scale_factor=2, mode='nearest'); x = torch.cat([x, skip], 1);
+ * x = conv(x)` (third-party, absent; called at /root/reference/utils/eval.py:51,199-200 through `model.decoder(...)`;
+ * /root/reference/eval_tumorbed.py:21-28 builds it).  up_pf: PF tensor (n, h/2, w/2, c_up); skip_pf: PF tensor (n, h, w, c_skip) or
+ * NULL with c_skip = 0; wpk: wsi_prepack_conv of the (cout, c_up + c_skip, 3, 3) weights in cat order; out_pf: (n, h, w, cout).
+ * -EINVAL when the shape's kernel has no fused form (the caller then materialises the concatenated tensor). */
+int wsi_conv3x3_up_concat_bn_act(const void* up_pf, const void* skip_pf, void* out_pf, const void* wpk, const float* bias, int n, int h, int w,
+                                 int c_up, int c_skip, int cout, int relu, int planes, void* stream);
 int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf, const void* wpk3, const float* bias3,
                            const void* wpk1, const float* bias1, int n, int h_in, int w_in, int cin, int cout, int planes,
                            void* stream);
@@ -118,7 +126,10 @@ int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* 
  * segment of the block's second conv (mode 3), +4096 layer-1 kernel without paired-tile LDS addressing, +16384 the trunk keeps
  * 128-byte lines for the stem output and the layer-1 tensors (mode 3 default: 96-byte lines there - the hi6 plane is rebuilt
  * in LDS by the layer-1 kernel; bit-identical results), +32768 the wide stride-2 kernel with 128 instead of 256 output channels
- * per workgroup on the layer-3 / layer-4 entries (mode 3; bit-identical).  Process-wide. */
+ * per workgroup on the layer-3 / layer-4 entries (mode 3; bit-identical), +1024 the 64-channel layer 1 on the r03 slab3 kernel instead of
+ * the row-stacked kernel (mode 3, 64-wide maps; results equal to a few ulps of the fp32 sums: another summation order), +65536 the
+ * U-Net decoder blocks write the upsampled + concatenated tensor before their first conv instead of reading both sources in it
+ * (bit-identical).  Process-wide. */
 int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */

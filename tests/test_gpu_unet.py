@@ -130,3 +130,48 @@ def test_predict_tumorbed_seg_and_predict_wsis_with_unet(dev, sd, tmp_path):
     tb_pred, outline = P.tumor_bed(p)                                # post-process: bit-exact given the device's own class map
     assert np.array_equal(out['tumor_bed'].cpu().numpy(), tb_pred) and np.array_equal(out['outline'].cpu().numpy(), outline)
     assert float((p != np.argmax(ref_w, 0)).mean()) <= 0.002
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64, 32, 16, 24), (2, 32, 0, 32, 40, 72), (2, 256, 128, 128, 8, 8), (2, 256, 128, 128, 32, 32), (1, 128, 64, 64, 12, 20),
+                                   (5, 512, 256, 256, 4, 4)])
+def test_fused_upsample_concat_conv_is_bit_identical(dev, shape):
+    """r04: the first conv of a decoder block reads the low-resolution tensor and the skip directly (nearest x2 upsample + concat as
+    source addresses of its slab DMA, wsi_conv3x3_up_concat_bn_act) - the same bits as materialising cat(up2(x), skip) first and
+    running the same kernel on it (the copy moved whole 128-byte lines: no arithmetic either way); pad positions stay untouched.
+    Shapes: (n, c_up, c_skip, cout, h, w) of the OUTPUT map - ragged tiles, no skip (the last block), 32 / 64 / 128 / 256 couts."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from wsi_segmentation_pipeline_amd import native, engine as E
+    lib = native.load()
+    n, cu, cs, co, h, w = shape
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(n * 13 + cu + h)
+    xu = torch.randn(n, cu, h // 2, w // 2, generator=g).abs_()
+    xs = torch.randn(n, cs, h, w, generator=g).abs_() if cs else None
+    wt = torch.randn(co, cu + cs, 3, 3, generator=g) * (2.0 / (9 * (cu + cs))) ** 0.5
+    cat = F.interpolate(xu, scale_factor=2, mode='nearest')
+    if cs:
+        cat = torch.cat([cat, xs], 1)
+    ran = 0
+    for planes in (3, 2):
+        wpk, bias = E.prepack_conv(wt, None, planes, dev)
+        up_pf = E.pf_pack(xu.to(dev), planes)
+        sk_pf = E.pf_pack(xs.to(dev), planes) if cs else None
+        cat_pf = E.pf_pack(cat.to(dev), planes)
+        out = E.pf_zeros(n, co, h, w, planes, dev)
+        rc = lib.wsi_conv3x3_up_concat_bn_act(up_pf.data_ptr(), sk_pf.data_ptr() if cs else None, out.data_ptr(), wpk.data_ptr(), bias.data_ptr(),
+                                              n, h, w, cu, cs, co, 1, planes, st)
+        assert rc == 0, (shape, planes, rc)
+        # the unfused route on a slab3 configuration (every stride-1 kernel but the row-stacked one gives the same bits)
+        ref = E.pf_zeros(n, co, h, w, planes, dev)
+        cfg = 30 if co % 128 == 0 else (31 if co % 64 == 0 else 90)
+        rc = lib.wsi_conv3x3_bn_act_cfg(cat_pf.data_ptr(), ref.data_ptr(), None, wpk.data_ptr(), bias.data_ptr(), n, h, w, cu + cs, co, 1, 1, planes, cfg, st)
+        if rc == -22 and cfg == 90:
+            rc = lib.wsi_conv3x3_bn_act_cfg(cat_pf.data_ptr(), ref.data_ptr(), None, wpk.data_ptr(), bias.data_ptr(), n, h, w, cu + cs, co, 1, 1, planes, 91, st)
+        assert rc == 0, (shape, planes, cfg, rc)
+        assert torch.equal(out, ref), (shape, planes)
+        got = E.pf_unpack(out, n, co, h, w, planes)
+        want = F.relu(F.conv2d(cat, wt, None, 1, 1))
+        assert float((got.cpu() - want).abs().max() / want.abs().max()) <= (2e-3 if planes == 3 else 2e-4)
+        ran += 1
+    assert ran == 2

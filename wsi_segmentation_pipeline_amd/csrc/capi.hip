@@ -372,8 +372,8 @@ extern "C" int wsi_study_set_debug(void* dev_buf) { g_study_debug = dev_buf; ret
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
                        int cfg = -1, int split_out = 0, long long split_pixels = 0, const void* in2 = nullptr, int in2_c = 0,
-                       const void* wpk2 = nullptr, const float* bias2 = nullptr, int line_flags = 0) {
-    if (!in_pf || !out_pf || !wpk || !bias || in_pf == out_pf || n <= 0) return WSI_EINVAL;
+                       const void* wpk2 = nullptr, const float* bias2 = nullptr, int line_flags = 0, const void* in_up = nullptr, int up_c = 0) {
+    if ((!in_pf && !(in_up && up_c == cin)) || !out_pf || !wpk || !bias || in_pf == out_pf || in_up == out_pf || n <= 0) return WSI_EINVAL;
     // 96-byte lines (CONV_IN96 / OUT96 / RESID96): mode 3, stride-1 3x3, 64 channels in and out (the slab3 kernel), no phase split
     if (line_flags && (planes != 3 || stride != 1 || ksize != 3 || cin != 64 || cout != 64 || (split_out && (line_flags & CONV_OUT96)) ||
                        (line_flags & ~(CONV_IN96 | CONV_OUT96 | CONV_RESID96)) || ((line_flags & CONV_RESID96) && !resid_pf)))
@@ -400,6 +400,10 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
 #endif
     a.flags |= line_flags;
     a.out2 = nullptr; a.wpk2 = nullptr; a.bias2 = nullptr;
+    if (in_up) {                                       // fused nearest x2 upsample + concat input (common.h ConvArgs.in_up): stride-1 3x3, slab3 kernels
+        if (stride != 1 || ksize != 3 || h_in % 2 || w_in % 2 || up_c <= 0 || up_c > cin || resid_pf || in2 || line_flags || split_out) return WSI_EINVAL;
+        a.in_up = in_up; a.up_c = up_c; a.gup = pf_geom_fd(n, h_in / 2, w_in / 2, up_c);
+    }
     if (in2) {                                         // extra K segment (common.h ConvArgs.in2): mode 3, stride-1 3x3, wide kernel only
         if (planes != 3 || stride != 1 || ksize != 3 || resid_pf || !wpk2 || !bias2 || in2_c <= 0 || in2_c % 32 || cout % 128 || cfg >= 0) return WSI_EINVAL;
         a.in2 = in2; a.in2_c = in2_c; a.wpk2 = wpk2; a.bias2 = bias2;
@@ -469,6 +473,13 @@ int wsi_conv3x3_bn_act_cfg(const void* in_pf, void* out_pf, const void* resid_pf
     return conv_common(in_pf, out_pf, resid_pf, wpk, bias, n, h_in, w_in, cin, cout, stride, 3, relu, planes, stream, cfg);
 }
 
+int wsi_conv3x3_up_concat_bn_act(const void* up_pf, const void* skip_pf, void* out_pf, const void* wpk, const float* bias, int n, int h, int w,
+                                 int c_up, int c_skip, int cout, int relu, int planes, void* stream) {
+    if (!up_pf || c_up <= 0 || c_skip < 0 || (c_skip > 0 && !skip_pf)) return WSI_EINVAL;
+    return conv_common(c_skip ? skip_pf : nullptr, out_pf, nullptr, wpk, bias, n, h, w, c_up + c_skip, cout, 1, 3, relu, planes, stream, -1, 0, 0,
+                       nullptr, 0, nullptr, nullptr, 0, up_pf, c_up);
+}
+
 int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf, const void* wpk3, const float* bias3,
                            const void* wpk1, const float* bias1, int n, int h_in, int w_in, int cin, int cout, int planes,
                            void* stream) {
@@ -492,11 +503,13 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
 
 extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_ranges, g_slab_pair;
 extern int g_l1_lines96, g_s2_nt4, g_l1_rows;
+extern int g_unet_fuse_up;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
     g_ds_fold = (s2_slab & 2048) ? 0 : 1;
     g_slab_pair = (s2_slab & 4096) ? 0 : 1;
     g_l1_rows = (s2_slab & 1024) ? 0 : 1;
+    g_unet_fuse_up = (s2_slab & 65536) ? 0 : 1;
     g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_s2_nt4 = (s2_slab & 32768) ? 0 : 1;
     g_xcd_ranges = (s2_slab & 256) ? 0 : (s2_slab & 512) ? 1 : 2;          // +256: off, +512: 64-channel layer only
@@ -1018,6 +1031,7 @@ int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, cons
 // at channels 256/128/64/32/16 (stored padded to whole 128-byte lines - 32 channels in the split-precision modes, 64 in
 // speed mode; the padding channels carry zero weights), 1x1 head.
 static const int kUnetSkipC[5] = {256, 128, 64, 64, 0};      // encoder maps x3, x2, x1, x0 (and none for the last block)
+int g_unet_fuse_up = 1;                                  // A/B: wsi_conv_set_mode +65536 off
 struct UnetPlan {
     size_t x0, cat[5], mid[5], out[5], total;
     int r_h[5], r_w[5], cx[5];                               // resolution of block L; channels of its upsampled input
@@ -1065,12 +1079,23 @@ static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& 
     // caller's business: the record carries 2 * N * H * W * cin_stored * cout_stored * 9), 7 = upsample + concat glue, 8 = 1x1 head
     for (int L = 0; L < 5 && !rc; ++L) {
         const int H = u.r_h[L], W = u.r_w[L], cin = dw->cin[2 * L], cout = dw->cout[2 * L];
-        int pi = prof_open(st, 7, 0.0);
-        rc = wsi_upsample_concat_dispatch(x, L < 4 ? enc[L + 1] : nullptr, dec + u.cat[L], n, H / 2, W / 2, u.cx[L], kUnetSkipC[L], planes, st);
+        // r04: the block's first conv reads the low-resolution tensor and the skip directly (ConvArgs.in_up: nearest x2 upsample +
+        // concat as source addresses of its slab DMA) where the shape's kernel is the slab3 kernel; otherwise (EINVAL) the
+        // upsample_concat pass writes the concatenated tensor first, as in r02-r03
+        int pi = prof_open(st, 6, 2.0 * n * H * W * (double)cin * cout * 9);
+        rc = g_unet_fuse_up ? wsi_conv3x3_up_concat_bn_act(x, L < 4 ? enc[L + 1] : nullptr, dec + u.mid[L], dw->conv_w[2 * L], dw->conv_b[2 * L], n, H, W,
+                                                           u.cx[L], kUnetSkipC[L], cout, 1, planes, st)
+                            : WSI_EINVAL;
         prof_close(st, pi);
-        pi = prof_open(st, 6, 2.0 * n * H * W * (double)cin * cout * 9);
-        if (!rc) rc = conv_common(dec + u.cat[L], dec + u.mid[L], nullptr, dw->conv_w[2 * L], dw->conv_b[2 * L], n, H, W, cin, cout, 1, 3, 1, planes, st);
-        prof_close(st, pi);
+        if (rc == WSI_EINVAL) {
+            if (pi >= 0) g_prof.kind[pi] = 9;             // (a refused launch: its empty record is not a decoder conv)
+            pi = prof_open(st, 7, 0.0);
+            rc = wsi_upsample_concat_dispatch(x, L < 4 ? enc[L + 1] : nullptr, dec + u.cat[L], n, H / 2, W / 2, u.cx[L], kUnetSkipC[L], planes, st);
+            prof_close(st, pi);
+            pi = prof_open(st, 6, 2.0 * n * H * W * (double)cin * cout * 9);
+            if (!rc) rc = conv_common(dec + u.cat[L], dec + u.mid[L], nullptr, dw->conv_w[2 * L], dw->conv_b[2 * L], n, H, W, cin, cout, 1, 3, 1, planes, st);
+            prof_close(st, pi);
+        }
         pi = prof_open(st, 6, 2.0 * n * H * W * (double)cout * cout * 9);
         if (!rc) rc = conv_common(dec + u.mid[L], dec + u.out[L], nullptr, dw->conv_w[2 * L + 1], dw->conv_b[2 * L + 1], n, H, W, cout, cout, 1, 3, 1, planes, st);
         prof_close(st, pi);
@@ -1108,9 +1133,14 @@ int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights
     a.in_f32 = in_f32; a.slide = slide; a.slide_pitch = slide_pitch_bytes; a.SH = slide_h; a.SW = slide_w;
     a.origins = tile_xy; a.lut = lut; a.wpk = wt->stem_w; a.bias = wt->stem_b; a.out = (float*)(ws + p.stem_scratch);
     a.N = n; a.H = h; a.W = w; a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
-    const int pi = prof_open(st, 7, 0.0);                    // (glue: the unfused stem conv + its re-encode for the 128 x 128 skip)
-    rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
-    if (!rc) rc = wsi_nhwc_to_pf_dispatch(a.out, dec + u.x0, n, h / 2, w / 2, 64, planes, st);
+    const int pi = prof_open(st, 7, 0.0);                    // (glue: the unfused stem conv for the half-resolution skip x0)
+    if (g_unet_fuse_up) {                                    // r04: the conv kernel writes PF lines itself (was: f32 scratch + nhwc_to_pf pass)
+        a.out_pf = dec + u.x0; a.out_planes = planes;
+        rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
+    } else {
+        rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
+        if (!rc) rc = wsi_nhwc_to_pf_dispatch(a.out, dec + u.x0, n, h / 2, w / 2, 64, planes, st);
+    }
     prof_close(st, pi);
     if (rc) return rc;
     const void* enc[5] = {ws + stage_off[3], ws + stage_off[2], ws + stage_off[1], ws + stage_off[0], dec + u.x0};

@@ -137,6 +137,14 @@ struct ConvArgs {
     // out = relu(conv3x3(in) + bias + conv1x1(in2) + bias2), no downsample tensor, no residual read.  null = none.
     const void* in2 = nullptr;
     int in2_c = 0;
+    // Fused `F.interpolate(x, scale_factor=2, mode='nearest')` + `torch.cat([x, skip], 1)` of the U-Net decoder blocks
+    // (segmentation_models_pytorch DecoderBlock, called at /root/reference/utils/eval.py:199-200) as the conv's INPUT (slab3
+    // kernel, stride-1 3x3): the first up_c of the gi.C input channels are read from `in_up`, a PF tensor of HALF the map size
+    // (geometry gup: pixel (y, x) of the conv input = pixel (y >> 1, x >> 1) of in_up), the remaining gi.C - up_c from `in`, the
+    // skip tensor at full size with gi.C - up_c channels (null when up_c == gi.C).  null = ordinary input.
+    const void* in_up = nullptr;
+    int up_c = 0;
+    PFGeom gup = {};
 };
 
 // ConvArgs.flags.  Product flags first; the CONV_ABL_* / study ones only act in builds with -DWSI_STUDY (bottleneck
@@ -320,4 +328,8 @@ struct StemArgs {
     // base-256 digits with the normalisation and BN folded in (capi.hip wsi_prepack_stem_u8, stem.hip stem_pool_kernel<.., DIG>)
     const void* wpk_u8;        // [nt 2][kh 7][digit][lane 64][16] i8 + float scale[64], or null: LUT path
     const float* bias_u8;      // 64
+    // unfused conv kernel (stem_conv7x7_kernel): write the post-ReLU map as PF lines of `out_planes` instead of f32 NHWC into `out`
+    // (the U-Net's half-resolution skip x0; r04: was f32 scratch + a re-encode pass)
+    void* out_pf = nullptr;
+    int out_planes = 0;
 };

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const int ntile = nb * WN + wn;
     const int NC = CONV_STUDY(a, CONV_ABL_NO_MAINLOOP) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // study builds: epilogue only
     const bool in96 = PLANES == 3 && (a.flags & CONV_IN96);   // 96-byte input lines (common.h): 3 bytes per channel in memory, 128-byte lines in LDS
-    const size_t in_pixstride = (size_t)a.gi.C * (in96 ? 3 : PFmt<PLANES>::BPC);
+    const int ncup = a.in_up ? a.up_c / PFmt<PLANES>::CPL : 0;    // leading lines that come from the half-size tensor (U-Net decoder)
+    const size_t in_pixstride = (size_t)(a.gi.C - (a.in_up ? a.up_c : 0)) * (in96 ? 3 : PFmt<PLANES>::BPC);
     const int in_line = in96 ? 96 : 128;
     int xoff[MT], qs[MT];                                     // slab-local pixel / PF position of each tile row
     bool valid[MT];
@@ -196,14 +197,18 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const size_t slab_byte0 = (size_t)slab0 * in_pixstride;
     const size_t in_bytes = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * in_pixstride;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)a.in + slab_byte0), 0, (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000);
-    int xvoff;
+        (void*)((const char*)a.in + slab_byte0), 0, a.in ? (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff) : 0, 0x00020000);
+    int xvoff, upl, usl;
     bool xact = true;                                         // 96-byte lines: the lanes of the two hi6 slots fetch nothing
     {
         const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
         xvoff = Pl * (int)in_pixstride + (in96 ? mx96_piece(sl) : sl) * 16;
         if (in96) xact = mx96_stored(sl);
+        upl = Pl; usl = sl;
     }
+    const int up_pixstride = a.up_c * PFmt<PLANES>::BPC;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.in_up, 0, a.in_up ? (int)((size_t)pf_alloc_pixels(a.gup.N, a.gup.H, a.gup.W) * up_pixstride) : 0, 0x00020000);
     // study hook (tools/tune_conv.py --wcopies): bits 10-13 of relu = number of back-to-back copies of the packed
     // weights minus one; workgroups spread over the copies (do hot weight lines serialise on few L2 channels?)
     const size_t wcopy = (size_t)(mtile % ((CONV_STUDY(a, 15 << CONV_WCOPIES_SHIFT) >> CONV_WCOPIES_SHIFT) + 1)) * (size_t)(a.go.C / 32) * NC * 9 * 4096;
@@ -251,8 +256,23 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
         // slab pieces by buffer addressing: a round of NTHREADS pieces is NTHREADS / 8 pixels, a multiple of 16, so the swizzle
         // term ((Pl >> 1) & 7) of a lane does not depend on the round - one per-lane byte offset (computed once per tile),
         // everything else scalar (r02: the 64-bit per-piece address arithmetic was ~10 % of this kernel's vector instructions)
-        for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-            if (xact) dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
+        if (c < ncup) {
+            // line of the up-sampled tensor (ConvArgs.in_up): the piece of slab pixel Pl comes from pixel (y >> 1, x >> 1) of the
+            // half-size tensor; pad / guard positions of the slab read pixel 0 of it (a zero guard).  One magic division pair per piece
+            for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r) {
+                const int rel = slab0 + upl + r * (NTHREADS / 8) - a.gi.G;
+                int src = 0;
+                if (rel >= 0 && rel < a.gi.NS) {
+                    const int n = fd_div(rel, a.gi.dS), rem = rel - n * a.gi.S;
+                    const int y = fd_div(rem, a.gi.dP), x = rem - y * P;
+                    if (x != a.gi.W && y != a.gi.H) src = a.gup.G + n * a.gup.S + (y >> 1) * a.gup.P + (x >> 1);
+                }
+                dma16_buf(urs, smem + (size_t)i0 * 16, src * up_pixstride + usl * 16, c * 128);
+            }
+        } else {
+            for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
+                if (xact) dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, (c - ncup) * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a; st_a = __builtin_readcyclecounter();)
@@ -363,6 +383,13 @@ static int launch_slab3(const ConvArgs& a, hipStream_t st) {
     if (lds < (size_t)WM * WN * 8192) lds = (size_t)WM * WN * 8192;          // the epilogue stages residual tiles there (8 KB per wave)
     if (lds > 160 * 1024) return WSI_EINVAL;
     if (PAIR && (!DENSE || MT % 2 || a.gi.W % 64 || ((long long)a.gi.N * a.gi.H * a.gi.W) % BM)) return WSI_EINVAL;
+    if (a.in_up) {                                           // fused upsample + concat input (common.h): 32-bit offsets into the half-size tensor
+        constexpr int CPL = PFmt<PLANES>::CPL;
+        if (a.up_c <= 0 || a.up_c % CPL || a.up_c > a.gi.C || (a.up_c < a.gi.C && !a.in) || a.gup.H * 2 != a.gi.H || a.gup.W * 2 != a.gi.W ||
+            a.gup.N != a.gi.N || (a.flags & (CONV_IN96 | CONV_RESID96)) || a.in2 ||
+            (size_t)pf_alloc_pixels(a.gup.N, a.gup.H, a.gup.W) * a.up_c * PFmt<PLANES>::BPC > (size_t)0x7fffffff)
+            return WSI_EINVAL;
+    }
     auto k = conv3x3s1_slab3_kernel<MT, WM, WN, PLANES, MINW, DENSE, ABL, PAIR>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1303,6 +1330,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
     if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 42) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 90)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
     if ((a.flags & CONV_IN96) && !((cfg >= 20 && cfg < 42) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // 96-byte input lines: slab3 / row-stacked kernels only
+    if (a.in_up && !((cfg >= 20 && cfg < 40) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // fused upsample + concat input: slab3 kernels only
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
     if (cfg >= 70 && cfg < 90) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
     // cfg 90: 512 px x 32 couts (8 x 1 waves, two pixel tiles each) for 32-channel outputs (U-Net decoder levels 4-5)
@@ -1354,6 +1382,9 @@ int g_wide_min_c = 128;                                  // channel count from w
                                                          // (r01: 3-8 % faster than cfg 30 on layers 2-4; A/B via wsi_conv_set_mode)
 static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {           // r01 / r02 tunes: profiles/r0*_tune_conv*.log
     if (a.go.C % 64) return fallback ? 91 : 90;              // 32 output channels
+    // fused upsample + concat input (U-Net decoder, ConvArgs.in_up): the slab3 kernels have the two-source slab DMA; on the
+    // 128-multiple shapes they are ~8 % slower than the wide kernel (r04 tune) and save the pass that writes the concatenated tensor
+    if (a.in_up) return a.go.C % 128 == 0 ? 30 : (a.gi.W > 128 && !fallback ? 39 : 31);
     // maps up to 4 x 4 (64 x 64 crops of the region-bag path: 25-56 % of a slab is padding): the small slab3 tiles keep four
     // workgroups per CU where the wide / ping-pong slabs leave one (r02 tune, n = 32000: 1.13 vs 1.28 ms at 4 x 4, 0.94 vs 1.15 at 2 x 2)
     if (a.gi.W <= 4 && a.go.C % 128 == 0 && planes == 3) return 30;
@@ -1390,7 +1421,7 @@ int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st) {
         if (a.gi.H != a.go.H || a.gi.W != a.go.W || a.gi.N != a.go.N) return WSI_EINVAL;
         if (cfg >= 0) return wsi_slab_dispatch_cfg(a, planes, cfg, st);
         const int rc = wsi_slab_dispatch_cfg(a, planes, slab_default_cfg(a, planes, false), st);
-        return rc != WSI_EINVAL ? rc : wsi_slab_dispatch_cfg(a, planes, slab_default_cfg(a, planes, true), st);
+        return rc != WSI_EINVAL ? rc : wsi_slab_dispatch_cfg(a, planes, slab_default_cfg(a, planes, true), st);   // (in_up: EINVAL unless the shape's kernel is slab3)
     }
     if ((a.ksize == 3 || a.ksize == 1) && (a.stride == 1 || a.stride == 2)) {
         if (a.go.H * a.stride != a.gi.H || a.go.W * a.stride != a.gi.W || a.gi.N != a.go.N) return WSI_EINVAL;

@@ -106,9 +106,71 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemArgs a) {
                     acc[nt][mt] = mfma_bf16(wf[nt][0], xf[mt][0], acc[nt][mt]);
                 }
         }
-        // ---- epilogue: bias + ReLU -> f32 NHWC -------------------------------------------------
+        // ---- epilogue: bias + ReLU -> PF lines (a.out_pf) or f32 NHWC --------------------------
         const int ox = ox0 + l31;
-        if (ox < Wc) {
+        if (a.out_pf) {
+            // Lane (column, h) holds channels nt * 32 + 8g + 4h + i of its pixel: the conv kernels' accumulator layout, so the line
+            // encodes are theirs (conv_dev.h conv_epilogue_q / conv_epilogue_mx; pf_lines.h is the scalar reference form)
+            const PFGeom go = pf_geom(a.N, Hc, Wc, 64);
+            const int bpc = a.out_planes == 1 ? 2 : 4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int oy = oy0 + 2 * wave + mt;
+                char* o = (char*)a.out_pf + (size_t)(go.G + n * go.S + oy * go.P + (ox < Wc ? ox : 0)) * (64 * bpc);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[nt][mt][r] + bias[nt][r], 0.f);
+                    if (a.out_planes == 3) {
+                        f32x16 hi, lo;
+                        f16x8 hv[2];
+                        float mh = 0.f, ml = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const float v0 = fminf(v[r], 65504.f), v1 = fminf(v[r + 1], 65504.f);
+                            const f16x2 hh = __builtin_convertvector(f32x2{v0, v1}, f16x2);
+                            hv[r >> 3][r & 7] = hh[0];
+                            hv[r >> 3][(r & 7) + 1] = hh[1];
+                            hi[r] = (float)hh[0];
+                            hi[r + 1] = (float)hh[1];
+                            lo[r] = v0 - hi[r];
+                            lo[r + 1] = v1 - hi[r + 1];
+                            mh = fmaxf(mh, fmaxf(hi[r], hi[r + 1]));
+                            ml = fmaxf(ml, fmaxf(fabsf(lo[r]), fabsf(lo[r + 1])));
+                        }
+                        pair_max2(mh, ml);                                      // (every lane takes part: the stores below are masked, not these)
+                        const int sh = mx6_scale_byte(mh), sl = mx6_scale_byte(ml);
+                        const int sb = h ? sh : sl;
+                        swap32_halves(lo, hi);
+                        const u32x6 q = mx6_pack32(lo, hi, sb ? mx_scale_value(sb) : 1.f);
+                        if (ox < Wc) {
+                            char* ol = o + nt * 128;
+                            *(f16x8*)(ol + 32 * h) = hv[0];
+                            *(f16x8*)(ol + 32 * h + 16) = hv[1];
+                            *(u32x4*)(ol + MX6_PLANE_LO(0) + 16 * h) = u32x4{q[0], q[1], q[2], q[3]};
+                            *(u32x4*)(ol + MX6_PLANE_HI(0) + 16 * h) = u32x4{q[4], q[5], (unsigned)sb, 0u};
+                        }
+                    } else if (ox < Wc) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            bf16x4 hi, lo;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                hi[i] = (__bf16)v[4 * g + i];
+                                lo[i] = (__bf16)(v[4 * g + i] - (float)hi[i]);
+                            }
+                            if (a.out_planes == 2) {
+                                *(bf16x4*)(o + nt * 128 + (8 * g + 4 * h) * 2) = hi;
+                                *(bf16x4*)(o + nt * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
+                            } else {
+                                *(bf16x4*)(o + (nt * 32 + 8 * g + 4 * h) * 2) = hi;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (ox < Wc) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int oy = oy0 + 2 * wave + mt;

@@ -55,6 +55,7 @@ SIGNATURES = {
     'wsi_conv3x3s2_ds_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'wsi_pf_split_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'wsi_conv3x3_bn_act_split': (_i, [_vp] * 5 + [_i] * 7 + [_vp]),
+    'wsi_conv3x3_up_concat_bn_act': (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
     'wsi_conv3x3s2_ds_fused_split': (_i, [_vp] * 7 + [_i] * 6 + [_vp]),
     'wsi_conv_set_mode': (_i, [_i]),
     'wsi_conv1x1_bn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
