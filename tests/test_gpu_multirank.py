@@ -124,7 +124,7 @@ def test_two_ranks_with_fewer_tiles_than_ranks(ntiles):
 
 
 # ------------------------------------------------------------------------------ region bags over two ranks (cfg4)
-def _regions(rank, world):
+def _regions(rank, world, precision='parity'):
     import myargs
     import resnets_shift
     import utils.eval as val
@@ -142,19 +142,24 @@ def _regions(rank, world):
         ys, xs = np.nonzero(rng.random(label_shape) < 0.02 * (rid + 1))
         metadata[rid] = {'cnt_xy': rng.integers(8, [88, 56], (10, 2)), 'perim_xy': rng.integers(8, [88, 56], (12, 2)),
                          'wsipath': 'unused', 'scan_level': 2, 'foreground_indices': (ys, xs), 'tile_id': rid}
-    model = resnets_shift.resnet18(False, precision='parity')
+    model = resnets_shift.resnet18(False, precision=precision)
     model.load_state_dict(W.make_resnet18_state_dict(11))
     model = model.cuda().eval()
     it = GenerateIterator_eval(metadata, scan=slide)
     assert len(it.dataset) == 11
-    return val.predict_regions(model, it, metadata, label_shape, rank=rank, world=world)
+    out = val.predict_regions(model, it, metadata, label_shape, rank=rank, world=world)
+    if precision == 'auto' and world > 1:
+        rep = model.hip_engine(torch.device('cuda', torch.cuda.current_device())).report
+        assert rep['scope'] == 'regions' and rep['mode'] in ('mx', 'parity'), rep      # ONE collective decision from the shard-wide probe
+        return out, rep['mode'], rep['probe_error']
+    return out
 
 
-def _regions_worker(rank, world, port, q):
+def _regions_worker(rank, world, port, q, precision='parity'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    q.put((rank, _regions(rank, world)))
+    q.put((rank, _regions(rank, world, precision)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -174,6 +179,25 @@ def test_two_rank_region_bags_equal_single_rank():
     for p in procs:
         p.join(120)
     assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+
+
+def test_two_rank_region_bags_auto_precision_is_one_decision():
+    """precision='auto' over two ranks (r03 advisor finding): the probe is a stratified sample over each rank's WHOLE shard of bags,
+    its maximum is all-reduced, and both ranks run - and report - the same mode; the painted label image equals the single-rank
+    one of that mode."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_regions_worker, args=(r, 2, port, q, 'auto')) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+    (m0, mode0, err0), (m1, mode1, err1) = got[0], got[1]
+    assert mode0 == mode1 and err0 == err1, (mode0, mode1, err0, err1)          # the all-reduced probe error, the same decision
+    ref = _regions(0, 1, mode0)
+    assert np.array_equal(m0, ref) and np.array_equal(m1, ref)
 
 
 # ------------------------------------------------------------------------------ dense 'seg' mode over two ranks
