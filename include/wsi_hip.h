@@ -253,11 +253,18 @@ int wsi_resample_tiles(const wsi_resample_plan* plan, const uint8_t* slide, long
  *   wsi_kmeans_points          utils/regiontools.py:89 key points: Lloyd iterations from the caller's initial centres on integer
  *                              (x, y) points, float64 distances, ties to the lower index, exact integer sums, empty clusters keep
  *                              their centre, stops when no label changes (the reference's sklearn MiniBatchKMeans is RNG / version
- *                              dependent: own deterministic spec); scratch: (3 k + 1) * 8 bytes.  Synchronises the stream. */
+ *                              dependent: own deterministic spec); scratch: (3 k + 1) * 8 bytes.  Synchronises the stream.  On
+ *                              return the scratch holds the last assignment's exact per-cluster sums: {sum x, sum y, count} as int64
+ *                              triples - what a caller needs to compare two partitions exactly.
+ *   wsi_kmeans_seed_farthest   r04: farthest-point initial centres for wsi_kmeans_points (the point farthest from the floor-mean,
+ *                              then k - 1 times the point farthest from its nearest seed; exact integers, ties to the lower index);
+ *                              scratch: n * 8 bytes.  The key points are the better of two Lloyd runs (raster-stratified and
+ *                              farthest-point seeds; smaller within-cluster sum of squares, compared exactly). */
 int wsi_find_nuclei_hsv(const uint8_t* rgb, long long npix, int pixel_stride, double mu_percent, uint8_t* mask_out, void* stream);
 size_t wsi_connected_components_scratch_bytes(int h, int w);
 int wsi_connected_components(const uint8_t* mask, int h, int w, int* labels_out, int* count_out, void* scratch, void* stream);
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream);
+int wsi_kmeans_seed_farthest(const int* points_xy, int n, int k, double* centres_xy_out, void* scratch, void* stream);
 /* utils/preprocessing.py:88-92 find_nuclei(mode='lab'): mask = a > (1 + mu_percent) * mean(a), a = the second channel of skimage's
  * rgb2lab (own deterministic spec: a in 2^-20 fixed point, exact mean; parity unpinned).  scratch: 16 + 4 * npix bytes.
  * utils/preprocessing.py:101-106 fill_mask: wsi_fill_holes = scipy.ndimage.binary_fill_holes (background components, 4-connected,

@@ -70,18 +70,21 @@ def inertia(coords, centres):
     return float(d.min(1).sum())
 
 
-# Measured in the build container (sklearn 1.7.2; `pytest -s` prints the table):
+# Measured in the build container (sklearn 1.7.2; `pytest -s` prints the table).  r04 first quantified the r01-r03 rule (ONE
+# raster-stratified seeding): matched-centre distance max 16.2 / 0.2 / 16.3 / 14.0 / 37.5 px, objective 1.626 / 0.998 / 0.916 / 0.990 /
+# 1.343 x sklearn's.  With the best of two seedings (stratified and farthest-point, r04):
 #   case            points  k   matched-centre distance max / mean (px)   inertia ours / sklearn
-#   seed5_us4_k3      120    3        16.2 / 10.3                              1.626
-#   seed0_us4_k3      116    3         0.2 /  0.2                              0.998
+#   seed5_us4_k3      120    3         0.2 /  0.1                              0.999
+#   seed0_us4_k3      116    3         0.2 /  0.1                              0.998
 #   seed1_us2_k5      651    5        16.3 /  7.2                              0.916
-#   seed2_us4_k8      118    8        14.0 /  2.3                              0.990
-#   seed7_us2_k12     620   12        37.5 /  8.9                              1.343
-# i.e. on blob-shaped regions the two land in DIFFERENT local minima of the same objective in four cases of five (either may
-# be the better one): centre points, and with them the 64 x 64 crops of cfg4, are not the reference's.  A full-batch Lloyd
-# iteration started from sklearn's centres moves them by <= 0.8 px - the objective and the update rule agree, the seeds do not.
+#   seed2_us4_k8      118    8         0.8 /  0.2                              0.974
+#   seed7_us2_k12     620   12        39.2 /  4.3                              1.096
+# i.e. three regions now agree with sklearn to under a pixel; in the other two the answers are DIFFERENT local minima of the same
+# objective (ours the better one in one of them): centre points, and with them the 64 x 64 crops of cfg4, are still not guaranteed
+# to be the reference's.  A full-batch Lloyd iteration started from sklearn's centres moves them by <= 0.8 px - the objective and
+# the update rule agree, the seeds do not.
 KMEANS_MAX_PX = 40.0            # bound on the matched-centre distance (the regions are 24 x 32 .. 48 x 64 down-sampled pixels)
-KMEANS_MAX_INERTIA_RATIO = 1.65
+KMEANS_MAX_INERTIA_RATIO = 1.10
 
 
 def test_kmeans_deviation_from_sklearn_is_bounded(golden_dir):

@@ -33,6 +33,7 @@ int wsi_lab_mask_dispatch(const uint8_t* rgb, long long npix, int stride, double
 size_t wsi_fill_holes_scratch_bytes_impl(int H, int W);
 int wsi_fill_holes_dispatch(const uint8_t* mask, int H, int W, uint8_t* out, void* scratch, hipStream_t st);
 int wsi_kmeans_dispatch(const int* pts, int n, double* centres, int k, int iters, int* labels, void* scratch, hipStream_t st);
+int wsi_kmeans_seed_farthest_dispatch(const int* pts, int n, int k, double* centres, void* scratch, hipStream_t st);
 int wsi_exponent_span_dispatch(const float* v, long long n, int* out2, hipStream_t st);
 int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* thresh, double* probs, uint8_t* classes,
                          const uint8_t* mask, int heat_mode, uint8_t* heat, hipStream_t st);
@@ -622,6 +623,11 @@ int wsi_slic(const uint8_t* rgb, int h, int w, const double* gauss_weights, int 
 int wsi_kmeans_points(const int* points_xy, int n, double* centres_xy, int k, int max_iters, int* labels_out, void* scratch, void* stream) {
     if (!points_xy || !centres_xy || !labels_out || !scratch) return WSI_EINVAL;
     return wsi_kmeans_dispatch(points_xy, n, centres_xy, k, max_iters, labels_out, scratch, (hipStream_t)stream);
+}
+
+int wsi_kmeans_seed_farthest(const int* points_xy, int n, int k, double* centres_xy_out, void* scratch, void* stream) {
+    if (!points_xy || !centres_xy_out || !scratch) return WSI_EINVAL;
+    return wsi_kmeans_seed_farthest_dispatch(points_xy, n, k, centres_xy_out, scratch, (hipStream_t)stream);
 }
 
 long long wsi_tile_grid_candidates(int iw, int ih, int ph, int pw, int sh, int sw) { return wsi_tile_grid_candidates_impl(iw, ih, ph, pw, sh, sw); }

@@ -132,6 +132,72 @@ __global__ void kmeans_update_kernel(double* centres, int k, const unsigned long
     }
 }
 
+// Farthest-point seeds (r04; oracle/proposals_oracle.py kmeans_seed_farthest): the point farthest from the floor-mean, then k - 1
+// times the point whose squared distance to the nearest seed is largest; exact integers, every tie to the lower raster index.
+// One workgroup (the point sets are region thumbnails: 10^2 .. 10^5 points, k <= a few dozen); dmin: n int64 of scratch.
+__global__ __launch_bounds__(1024) void kmeans_seed_farthest_kernel(const int* pts, int n, int k, double* centres, long long* dmin) {
+    __shared__ long long rv[1024];
+    __shared__ int ri[1024];
+    __shared__ long long sh[2];
+    const int tid = threadIdx.x;
+    auto argmax_block = [&](long long v, int i) {             // largest value, lowest index among equals -> ri[0]
+        rv[tid] = v; ri[tid] = i;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if (tid < s) {
+                const long long v2 = rv[tid + s];
+                const int i2 = ri[tid + s];
+                if (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid])) { rv[tid] = v2; ri[tid] = i2; }
+            }
+            __syncthreads();
+        }
+    };
+    long long sx = 0, sy = 0;
+    for (int i = tid; i < n; i += 1024) { sx += pts[2 * i]; sy += pts[2 * i + 1]; }
+    rv[tid] = sx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) rv[tid] += rv[tid + s]; __syncthreads(); }
+    if (tid == 0) sh[0] = rv[0];
+    __syncthreads();
+    rv[tid] = sy;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) rv[tid] += rv[tid + s]; __syncthreads(); }
+    if (tid == 0) sh[1] = rv[0];
+    __syncthreads();
+    // floor division (the sums of pixel coordinates are >= 0)
+    const long long cx = sh[0] / n, cy = sh[1] / n;
+    long long bv = -1;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 1024) {
+        const long long dx = pts[2 * i] - cx, dy = pts[2 * i + 1] - cy, d = dx * dx + dy * dy;
+        if (d > bv) { bv = d; bi = i; }                       // ascending i per thread: the first maximum stays
+    }
+    argmax_block(bv, bi);
+    int seed = ri[0];
+    __syncthreads();
+    if (tid == 0) { centres[0] = (double)pts[2 * seed]; centres[1] = (double)pts[2 * seed + 1]; }
+    for (int c = 1; c <= k; ++c) {                            // pass c: fold seed c - 1 into dmin, pick seed c (c < k)
+        const long long qx = pts[2 * seed], qy = pts[2 * seed + 1];
+        bv = -1; bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            const long long dx = pts[2 * i] - qx, dy = pts[2 * i + 1] - qy, d = dx * dx + dy * dy;
+            const long long m = c == 1 ? d : (d < dmin[i] ? d : dmin[i]);
+            dmin[i] = m;
+            if (m > bv) { bv = m; bi = i; }
+        }
+        if (c == k) break;
+        argmax_block(bv, bi);
+        seed = ri[0];
+        __syncthreads();
+        if (tid == 0) { centres[2 * c] = (double)pts[2 * seed]; centres[2 * c + 1] = (double)pts[2 * seed + 1]; }
+    }
+}
+int wsi_kmeans_seed_farthest_dispatch(const int* pts, int n, int k, double* centres, void* scratch, hipStream_t st) {
+    if (n <= 0 || k <= 0 || k > n) return WSI_EINVAL;
+    hipLaunchKernelGGL(kmeans_seed_farthest_kernel, dim3(1), dim3(1024), 0, st, pts, n, k, centres, (long long*)scratch);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
 // ------------------------------------------------------------------------------------------ find_nuclei, the other modes
 // mode 'lab' (/root/reference/utils/preprocessing.py:88-92): a = rgb2lab(image)[..., 1]; mask = a > (1 + mu_percent) * mean(a).
 // skimage is absent: own deterministic specification (oracle/wsi_oracle.py find_nuclei_lab) - `a` in 2^-20 fixed point so that the

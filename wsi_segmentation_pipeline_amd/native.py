@@ -92,6 +92,7 @@ SIGNATURES = {
     'wsi_connected_components_scratch_bytes': (_sz, [_i, _i]),
     'wsi_connected_components': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     'wsi_kmeans_points': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'wsi_kmeans_seed_farthest': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'wsi_find_nuclei_lab': (_i, [_vp, _ll, _i, _d, _vp, _vp, _vp]),
     'wsi_fill_holes_scratch_bytes': (_sz, [_i, _i]),
     'wsi_fill_holes': (_i, [_vp, _i, _i, _vp, _vp, _vp]),

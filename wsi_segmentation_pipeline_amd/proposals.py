@@ -78,17 +78,34 @@ def _resize_nearest(img, out_hw):
     return img[ys][:, xs]
 
 
+def _partition_score(sums_host):
+    """sum_j |S_j|^2 / n_j of a partition as an exact fraction (the larger, the smaller its within-cluster sum of squares)."""
+    from fractions import Fraction
+    return sum((Fraction(int(sx) * int(sx) + int(sy) * int(sy), int(c)) for sx, sy, c in sums_host if c), Fraction(0))
+
+
 def kmeans(points_xy, k, iters=KMEANS_ITERS):
-    """(N,2) int32 GPU points (raster order) -> (centres (k,2) float64, labels (N,) int32) by the deterministic Lloyd spec."""
+    """(N,2) int32 GPU points (raster order) -> (centres (k,2) float64, labels (N,) int32) by the deterministic Lloyd spec:
+    two runs on the device - from the raster-stratified seeds of r01-r03 and from farthest-point seeds (wsi_kmeans_seed_farthest) -
+    and the partition with the smaller within-cluster sum of squares wins (exact comparison of the kernels' integer sums on the
+    host: 3 k numbers per run; ties to the stratified run).  oracle/proposals_oracle.py kmeans is the same rule."""
     lib = native.load()
     pts = points_xy.to(torch.int32).contiguous()
     n = pts.shape[0]
-    init = torch.tensor([(2 * j + 1) * n // (2 * k) for j in range(k)], device=pts.device)
-    centres = pts[init].to(torch.float64).contiguous()
-    labels = torch.empty(n, dtype=torch.int32, device=pts.device)
-    scratch = torch.empty((3 * k + 1) * 8, dtype=torch.uint8, device=pts.device)
-    native.check(lib.wsi_kmeans_points(_ptr(pts), n, _ptr(centres), k, iters, _ptr(labels), _ptr(scratch), _stream()), 'wsi_kmeans_points')
-    return centres, labels
+    runs = []
+    for seeding in ('stratified', 'farthest'):
+        if seeding == 'stratified':
+            init = torch.tensor([(2 * j + 1) * n // (2 * k) for j in range(k)], device=pts.device)
+            centres = pts[init].to(torch.float64).contiguous()
+        else:
+            centres = torch.empty((k, 2), dtype=torch.float64, device=pts.device)
+            dmin = torch.empty(n, dtype=torch.int64, device=pts.device)
+            native.check(lib.wsi_kmeans_seed_farthest(_ptr(pts), n, k, _ptr(centres), _ptr(dmin), _stream()), 'wsi_kmeans_seed_farthest')
+        labels = torch.empty(n, dtype=torch.int32, device=pts.device)
+        scratch = torch.empty(3 * k + 1, dtype=torch.int64, device=pts.device)
+        native.check(lib.wsi_kmeans_points(_ptr(pts), n, _ptr(centres), k, iters, _ptr(labels), _ptr(scratch), _stream()), 'wsi_kmeans_points')
+        runs.append((centres, labels, _partition_score(scratch[:3 * k].view(k, 3).cpu().tolist())))
+    return runs[1][:2] if runs[1][2] > runs[0][2] else runs[0][:2]
 
 
 def get_key_points(patch, us, min_clusters):
