@@ -1396,8 +1396,9 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     if (!fallback && planes == 1 && a.go.C % 256 == 0 && a.gi.W <= 8 && g_wide_min_c <= 256) return 70;
     // parity mode (r02 tune, n = 2000): the ping-pong kernel in its 256 px x 128 couts shape on layers 3-4 (1.48 / 1.38 vs 1.55 / 1.43 ms
     // for the wide kernel), slab3 on layer 2 (1.69 vs 1.78 ms)
-    if (!fallback && planes == 2 && a.go.C % 256 == 0 && g_wide_min_c <= 256) return 83;
-    if (planes == 2 && a.go.C == 128 && a.gi.W > 8 && g_wide_min_c <= 128) return 30;
+    // (r04: with its main-loop DMA through inline asm the wide kernel wins in parity mode too - n = 2000, with / without residual:
+    // layer 2 1.569 / 1.470 ms against slab3 1.628 / 1.528, layer 3 1.363 / 1.318 against ping-pong 1.434 / 1.363, layer 4 1.257 / 1.237
+    // against 1.288 / 1.256, profiles/r04_tune_parity.log - so the two parity rules of r02 are gone and the line below decides)
     if (a.go.C % 128 == 0 && a.go.C >= g_wide_min_c && !(planes == 1 && a.gi.W > 33)) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
     if (a.go.C % 128 != 0 && planes == 3 && !fallback && g_l1_rows && a.gi.W == 64 && a.gi.H % 4 == 0 && !a.in2) return 40;   // r04: row-stacked tiles (A/B: wsi_conv_set_mode +1024 off)
