@@ -1393,7 +1393,8 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     // with one (profiles/r03_tune_conv_mx.log).  Single-pass bf16 mode:
     // (r03 tune of that mode, n = 2000, with / without residual: wide 0.60 / 0.70 (layer 2), 0.50 / 0.56, 0.47 / 0.50 ms against
     // slab3 0.62 / 0.74 and ping-pong 0.52 / 0.59, 0.47 / 0.50: the wide kernel everywhere except 8x8 maps, where the two tie)
-    if (!fallback && planes == 1 && a.go.C % 256 == 0 && a.gi.W <= 8 && g_wide_min_c <= 256) return 70;
+    // (r04: on 8x8 maps in single-pass bf16 the wide kernel with asm DMA now beats the ping-pong kernel too: 0.499 / 0.471 ms against
+    // 0.507 / 0.477, profiles/r04_tune_parity.log - the rule that sent them to cfg 70 is gone)
     // parity mode (r02 tune, n = 2000): the ping-pong kernel in its 256 px x 128 couts shape on layers 3-4 (1.48 / 1.38 vs 1.55 / 1.43 ms
     // for the wide kernel), slab3 on layer 2 (1.69 vs 1.78 ms)
     // (r04: with its main-loop DMA through inline asm the wide kernel wins in parity mode too - n = 2000, with / without residual:
