@@ -66,7 +66,8 @@ def test_prepack_conv_roundtrip(lib):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     for planes in (1, 2):
         nbytes = lib.wsi_prepack_conv_bytes(cout, cin, k, planes)
-        assert nbytes == cout * cin * k * k * 2 * 2 // (2 // planes) // (1 if planes == 2 else 1) or nbytes > 0
+        nblocks = (cout // 32) * (cin * planes // 64) * k * k * 4096
+        assert nbytes == nblocks + (cout * 4 if planes == 2 else 0)      # mode 2: + the inverse per-channel weight scales
         pk = np.zeros(nbytes // 2, np.uint16)
         bias = np.zeros(cout, np.float32)
         assert lib.wsi_prepack_conv(p(w), p(g), p(b), p(m), p(v), 1e-5, cout, cin, k, planes, p(pk), p(bias)) == 0
@@ -75,7 +76,14 @@ def test_prepack_conv_roundtrip(lib):
         assert np.allclose(bias, b - m * scale, atol=1e-6)
         # unpack [ntile][line][tap][f][lane][8] back to OIHW and compare hi+lo against the folded weights
         nl = cin * planes // 64
-        frag = _bf16_to_f32(pk).reshape(cout // 32, nl, k * k, 4, 64, 8)
+        body = pk[:nblocks // 2]
+        if planes == 2:                                                  # fp16 pair of (weight x 2^e), max |.| per channel in [2^13, 2^14)
+            frag = body.view(np.float16).astype(np.float32).reshape(cout // 32, nl, k * k, 4, 64, 8)
+            inv = pk[nblocks // 2:].view(np.float32)
+            assert inv.shape == (cout,) and np.all(np.log2(inv) == np.round(np.log2(inv)))
+        else:
+            frag = _bf16_to_f32(body).reshape(cout // 32, nl, k * k, 4, 64, 8)
+            inv = np.ones(cout, np.float32)
         rec = np.zeros_like(wf)
         for nt in range(cout // 32):
             for l in range(nl):
@@ -85,7 +93,11 @@ def test_prepack_conv_roundtrip(lib):
                         co = nt * 32 + (lane & 31)
                         ci = cbase + 8 * (lane >> 5)
                         rec[co, ci:ci + 8] += frag[nt, l, :, f, lane, :].T.reshape(8, k, k)
-        tol = 2 ** -16 if planes == 2 else 2 ** -8
+        if planes == 2:
+            amax = np.abs(rec).reshape(cout, -1).max(1)
+            assert np.all((amax >= 2.0 ** 13) & (amax < 2.0 ** 14))
+        rec = rec * inv[:, None, None, None]
+        tol = 2 ** -21 if planes == 2 else 2 ** -8                       # fp16 pair: 22 significand bits where lo is normal
         assert np.abs(rec - wf).max() <= tol * np.abs(wf).max()
 
 

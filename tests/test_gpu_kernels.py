@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL_PARITY = 1e-4      # relative to the tensor's max magnitude, bf16x2 split (3 MFMA passes)
+TOL_PARITY = 2e-5      # relative to the tensor's max magnitude, fp16 hi + fp16 lo pair (3 MFMA passes; r01-r04 bf16 pair: 1e-4)
 TOL_SPEED = 3e-2       # single-pass bf16
 TOL_MX = 1e-4          # fp16 main pass + MX-fp6 cross terms (mode 3), single layer (measured <= 3e-5)
 
@@ -26,7 +26,7 @@ def test_pf_roundtrip(dev):
     from wsi_segmentation_pipeline_amd import engine as E
     g = torch.Generator().manual_seed(0)
     x = torch.randn(3, 128, 5, 7, generator=g)
-    for planes, tol in ((2, 2 ** -16), (1, 2 ** -8), (3, 2 ** -13)):
+    for planes, tol in ((2, 2 ** -21), (1, 2 ** -8), (3, 2 ** -13)):      # planes 2: fp16 pair
         buf = E.pf_pack(x.to(dev), planes)
         y = E.pf_unpack(buf, 3, 128, 5, 7, planes).cpu()
         assert _rel_err(y, x) <= tol
@@ -61,7 +61,7 @@ def _conv_case(dev, n, cin, cout, h, w, stride, ksize, resid, relu, planes, seed
         real = E.pf_pack(torch.ones_like(got).to(dev), 3).view(-1, 128)[:, :64].ne(0).any(1)
         assert not bool(opf.view(-1, 128)[~real].ne(0).any()), 'kernel wrote to a pad position'
     else:
-        real = E.pf_pack(torch.full_like(got, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
+        real = E.pf_pack(torch.full_like(got, 1.0 + 2.0 ** -12).to(dev), planes).view(torch.int16) != 0
         assert not bool((opf.view(torch.int16)[~real] != 0).any()), 'kernel wrote to a pad position'
     return _rel_err(got, ref)
 
@@ -225,7 +225,7 @@ def test_fused_stride2_block_entry(dev, shape):
             real = E.pf_pack(torch.ones_like(g3).to(dev), 3).view(-1, 128)[:, :64].ne(0).any(1)
             assert not bool(o3.view(-1, 128)[~real].ne(0).any()) and not bool(o1.view(-1, 128)[~real].ne(0).any())
         else:
-            real = E.pf_pack(torch.full_like(g3, 1.0 + 2.0 ** -9).to(dev), planes).view(torch.int16) != 0
+            real = E.pf_pack(torch.full_like(g3, 1.0 + 2.0 ** -12).to(dev), planes).view(torch.int16) != 0
             assert not bool((o3.view(torch.int16)[~real] != 0).any()) and not bool((o1.view(torch.int16)[~real] != 0).any())
 
 
@@ -458,9 +458,9 @@ def test_stitch_exponent_guard(dev):
 
 
 def test_mx_clamp_to_fp16_range(dev):
-    """The documented deviation of mode 3: activations are clamped to the fp16 range (+-65504) when a conv writes its output
-    lines; parity mode carries the same values unclamped.  Centre-tap permutation weights of gain 300 on inputs up to 400
-    put outputs at up to 120000."""
+    """The documented deviation of the two split-precision modes: activations are clamped to the fp16 range (+-65504) when a conv
+    writes its output lines (mode 3 since r01; mode 2 since its operand pair became fp16 in r05).  Centre-tap permutation weights of
+    gain 300 on inputs up to 400 put outputs at up to 120000."""
     from wsi_segmentation_pipeline_amd import engine as E
     n, c, h, w = 2, 64, 8, 8
     g = torch.Generator().manual_seed(5)
@@ -475,8 +475,10 @@ def test_mx_clamp_to_fp16_range(dev):
         wpk, bias = E.prepack_conv(wt, None, planes, dev)
         out[planes] = E.pf_unpack(E.conv_bn_act(E.pf_pack(x.to(dev), planes), n, h, w, c, c, wpk, bias, 1, 3, None, False, planes),
                                   n, c, h, w, planes).cpu()
-    assert float((out[2] - ref).abs().max() / ref.abs().max()) <= TOL_PARITY               # parity: no clamp
     clamped = ref.clamp(-65504.0, 65504.0)
+    # parity (fp16 pair since r05; the bf16 pair of r01-r04 did not clamp): the same documented fp16-range saturation as mx
+    assert float(out[2].abs().max()) == 65504.0
+    assert float((out[2] - clamped).abs().max() / 65504.0) <= TOL_PARITY
     assert float(out[3].abs().max()) == 65504.0
     assert float((out[3] - clamped).abs().max() / 65504.0) <= TOL_MX
     inside = ref.abs() < 60000

@@ -1,7 +1,8 @@
 """GPU parity of the dense 'seg' model (ResNet-18 encoder + smp-style U-Net decoder on HIP kernels) against the torch-fp32 CPU
 spec oracle/unet_oracle.py.  The decoder belongs to a third-party package the reference only calls (absent, un-pinned):
 parity is unpinned by the reference, the spec is self-authored from the published architecture (oracle/unet_oracle.py header);
-the encoder half is pinned through resnet_oracle.  Tolerances are relative to the largest |logit| of the batch."""
+the encoder half is pinned through resnet_oracle.  The default mode (planes 2) is held to north_star's ABSOLUTE 1e-3 on logits of
+magnitude 16 (r05); mx / speed are reported against looser bounds and not claimed on the dense path."""
 import os
 
 import numpy as np
@@ -27,11 +28,26 @@ def sd():
     return W.make_unet_state_dict(7, 4)
 
 
-@pytest.mark.parametrize('planes,tol', [(2, 2e-4), (3, 3e-3), (1, 6e-2)])
-def test_unet_forward_matches_oracle(dev, sd, planes, tol):
+def _scaled_to_logit(sd, x, target=16.0):
+    """The seeded decoder ends in |logit| of a few hundred (softmax saturated everywhere).  The 1e-3 contract of north_star is ABSOLUTE on
+    logits of the size trained heads produce, so the final 1x1 conv is scaled until max |logit| of the spec == `target` on these inputs
+    (bench.py --workload seg does the same with 8 / 216) - the magnitude of the hot precision-margin families of the cls path."""
+    with torch.no_grad():
+        s = target / float(U.unet_forward(sd, x).abs().max())
+    sd = dict(sd)
+    for key in ('decoder.final_conv.weight', 'decoder.final_conv.bias'):
+        sd[key] = sd[key] * s
+    return sd
+
+
+# planes 2 (the drop-in default of UNetSeg): ABSOLUTE 1e-3 on per-pixel logits at |logit| = 16 - the contract.  mx / speed are reported
+# against looser bounds and are not claimed on the dense path (r04: mx 2.2e-3 at |logit| 16).
+@pytest.mark.parametrize('planes,tol,enc_tol', [(2, 1e-3, 5e-5), (3, 4.8e-2, 3e-3), (1, 1.0, 6e-2)])
+def test_unet_forward_matches_oracle(dev, sd, planes, tol, enc_tol):
     from wsi_segmentation_pipeline_amd.unet import UNetEngine
     u8 = W.make_u8_patches(41, (3, 3, 64, 96))
     x = R.normalize_u8(u8)
+    sd = _scaled_to_logit(sd, x)
     with torch.no_grad():
         ref = U.unet_forward(sd, x)
         enc_sd = {k[8:]: v for k, v in sd.items() if k.startswith('encoder.')}
@@ -39,21 +55,46 @@ def test_unet_forward_matches_oracle(dev, sd, planes, tol):
     eng = UNetEngine(sd, dev, planes=planes)
     got, enc = eng.forward_f32(x.to(dev), logits=True, enc=True)
     scale = float(ref.abs().max())
-    err = float((got.cpu() - ref).abs().max()) / scale
+    assert abs(scale - 16.0) < 1e-3
+    err = float((got.cpu() - ref).abs().max())
     enc_err = [float((a.cpu() - b).abs().max() / b.abs().max()) for a, b in zip(enc, ref_enc)]
-    print('planes %d: logits rel err %.2e (max |logit| %.1f); encoder maps rel err %s' % (planes, err, scale, ['%.1e' % e for e in enc_err]))
+    print('planes %d: max |logit - spec| %.2e ABSOLUTE at max |logit| %.1f; encoder maps rel err %s' % (planes, err, scale, ['%.1e' % e for e in enc_err]))
     assert got.shape == ref.shape == (3, 4, 64, 96)
-    assert err <= tol and max(enc_err) <= tol
+    assert err <= tol and max(enc_err) <= enc_tol
     # decoder alone on the oracle's encoder maps == the generic `model.decoder(model.encoder(x))` calling sequence
     dec = eng.decode([t.to(dev) for t in ref_enc])
-    assert float((dec.cpu() - ref).abs().max()) / scale <= tol
+    assert float((dec.cpu() - ref).abs().max()) <= tol
     # tiles read from a u8 slide (fused read + transform in the stems) == the f32 path
     strip = np.ascontiguousarray(u8.transpose(0, 2, 3, 1).reshape(-1, 96, 3))
     xy = np.stack((np.zeros(3, np.int32), np.arange(3, dtype=np.int32) * 64), 1)
     t = eng.forward_tiles(torch.from_numpy(strip).to(dev), torch.from_numpy(xy), 64, 96)
-    assert float((t.cpu() - ref).abs().max()) / scale <= tol
+    assert float((t.cpu() - ref).abs().max()) <= tol
     # argmax agreement of the class maps (what the drivers consume)
     assert float((got.cpu().argmax(1) != ref.argmax(1)).float().mean()) <= (0.002 if planes >= 2 else 0.05)
+
+
+def test_dense_logits_hold_the_absolute_contract_at_bench_shape(dev):
+    """The bench's own dense workload (bench.py --workload seg: decoder seed 5, final conv x 8/216, random u8 tiles of 256 x 256,
+    max |logit| ~ 16) in the drop-in's default mode: max |logit - spec| <= 1e-3 ABSOLUTE per pixel (r04's bf16 pair measured 1.011e-3
+    here and the relative tolerance of the r04 test did not see it; the fp16 pair of r05 is expected near 1e-4)."""
+    from wsi_segmentation_pipeline_amd.unet import UNetEngine
+    usd = W.make_unet_state_dict(5, classes=4)
+    for key in ('decoder.final_conv.weight', 'decoder.final_conv.bias'):
+        usd[key] = usd[key] * (8.0 / 216.0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    level0 = torch.randint(0, 256, (512, 512, 3), dtype=torch.uint8, device=dev, generator=g)
+    xy = torch.tensor([[0, 0], [256, 0], [0, 256], [256, 256]], dtype=torch.int32, device=dev)
+    eng = UNetEngine(usd, dev, planes=2)
+    got = eng.forward_tiles(level0, xy, 256, 256).cpu()
+    l0 = level0.cpu().numpy()
+    u8 = np.stack([l0[y:y + 256, x:x + 256] for x, y in xy.cpu().numpy()]).transpose(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = U.unet_forward(usd, R.normalize_u8(u8))
+    err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+    print('dense path, parity (fp16 pair): max |logit - spec| %.2e at max |logit| %.1f' % (err, scale))
+    assert 8.0 < scale < 40.0
+    assert err <= 1e-3
+    assert err <= 7e-4, 'round-5 target: 0.7 of the contract'
 
 
 def test_unet_256_batch_and_module_surface(dev, sd):

@@ -343,6 +343,7 @@ def _all_collectives_worker(rank, world, port, total, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     ok = {}
+    S.OP_LOG = []                                     # every collective of the path records (op, shape, dtype) here (slide._Wire)
     # (1) slide.gather_tile_logits: contiguous raster shares of `total` tiles
     full = torch.arange(total * 4, dtype=torch.float32).view(total, 4) * 0.5 - 3
     lo, hi = S.shard_range(total, rank, world)
@@ -377,7 +378,23 @@ def _all_collectives_worker(rank, world, port, total, q):
     sp = S.allreduce_span(span, torch.device('cpu')).tolist()
     ok['span'] = sp == [120 + min(owners), 130 - min(owners)]
     ok['max'] = S.allreduce_max(0.25 * rank if hi > lo else 0.0, torch.device('cpu'), world) == 0.25 * max(owners)
-    q.put((rank, ok))
+    # The op sequence.  RCCL and gloo run the SAME op list (slide._Wire: only the wire buffer's place differs), so what is asserted
+    # here on gloo is the list an 8-GPU RCCL run issues: collectives identical on every rank (shapes included - a mismatch is a
+    # hang on hardware), point-to-point ops only between the owners of map bands and rank 0.
+    chunk = (total + world - 1) // world
+    bchunk = max(len(s_) for s_ in shards)
+    log = list(S.OP_LOG)
+    coll = [e for e in log if e[0] not in ('send', 'recv')]
+    p2p = [e for e in log if e[0] in ('send', 'recv')]
+    ok['ops_head'] = coll[:3] == [('all_gather', (chunk, 4), 'float32'), ('all_gather', (bchunk, 4), 'float32'), ('all_reduce_sum', (4, 32, 32), 'float64')]
+    ok['ops_bands'] = coll[3][:1] == ('all_gather',) and coll[3][1:] == ((1,), 'int64') and coll[4][0] == 'all_gather' and coll[4][1][1] == 4
+    ok['ops_tail'] = coll[5:] == [('broadcast', (32, 32), 'uint8'), ('all_reduce_min', (1,), 'int32'), ('all_reduce_max', (1,), 'int32'),
+                                  ('all_reduce_max', (1,), 'float64')]
+    if rank == 0:
+        ok['ops_p2p'] = [e[0] for e in p2p] == ['recv'] * len([r for r in owners if r != 0])
+    else:
+        ok['ops_p2p'] = [e[0] for e in p2p] == (['send'] if hi > lo else [])
+    q.put((rank, (ok, coll)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -397,7 +414,8 @@ def test_collectives_uneven_and_empty_shards(world, total):
         p.join(60)
     assert sorted(res) == list(range(world))
     for r in range(world):
-        assert all(res[r].values()), (r, res[r])
+        assert all(res[r][0].values()), (r, res[r][0])
+        assert res[r][1] == res[0][1], 'rank %d issued other collectives than rank 0' % r     # same ops, same shapes, same order everywhere
 
 
 def test_bench_builds_eight_rank_environments(monkeypatch):

@@ -30,21 +30,19 @@ def shard_bags(costs, world):
 
 def gather_rows(local, shards, rank, world):
     """local (n_r, C) rows of this rank's shard -> (R, C) rows in original order on every rank: one all-gather of equal
-    padded chunks (payload R x C fp32: latency-bound, a single collective), then an index scatter."""
-    import torch.distributed as dist
+    padded chunks (payload R x C fp32: latency-bound, a single collective), then an index scatter.  The collective goes through
+    slide._Wire like every other one of the path: one op list for RCCL and gloo, only the wire buffer's place differs."""
     total = sum(len(s) for s in shards)
-    from .slide import _collective_forced
+    from .slide import _Wire, _collective_forced
     if world == 1 and not _collective_forced():
         out = torch.empty((total, local.shape[1]), dtype=local.dtype, device=local.device)
         out[torch.as_tensor(shards[0], device=local.device)] = local
         return out
     chunk = max(len(s) for s in shards)
-    via_host = dist.get_backend() != 'nccl' and local.is_cuda
-    buf = torch.zeros((chunk, local.shape[1]), dtype=local.dtype, device='cpu' if via_host else local.device)
-    buf[:local.shape[0]] = local
-    allb = torch.empty((world * chunk, local.shape[1]), dtype=local.dtype, device=buf.device)
-    dist.all_gather_into_tensor(allb, buf)
-    allb = allb.to(local.device)
+    wire = _Wire(local.device)
+    buf = wire.new((chunk, local.shape[1]), local.dtype, 0)
+    buf[:local.shape[0]] = wire.put(local)
+    allb = wire.get(wire.all_gather(wire.new((world * chunk, local.shape[1]), local.dtype), buf))
     out = torch.empty((total, local.shape[1]), dtype=local.dtype, device=local.device)
     for r in range(world):
         if len(shards[r]):

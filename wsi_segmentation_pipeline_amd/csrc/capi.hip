@@ -3,6 +3,8 @@
 #include "common.h"
 #include <mutex>
 #include <unordered_map>
+#include <vector>
+#include <cmath>
 #include "../../include/wsi_hip.h"
 #include <math.h>
 #include <string.h>
@@ -87,6 +89,13 @@ static inline uint16_t f16_bits(float x) {
     return u;
 }
 
+static inline void split_host_f16(float x, uint16_t& hi, uint16_t& lo) {   // the fp16 pair of mode 2 (common.h split_f16)
+    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    const float h = f16_round(x);
+    hi = f16_bits(h);
+    lo = f16_bits(x - h);
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 long long wsi_tile_grid_candidates_impl(int iw, int ih, int ph, int pw, int sh, int sw);
@@ -129,7 +138,8 @@ long long wsi_pf_pixel_index(int n, int y, int x, int h, int w) {
 size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes) {
     if (planes < 1 || planes > 3 || cout % 32 || cin % (planes == 1 ? 64 : 32) || (k != 1 && k != 3)) return 0;     // (whole 128-byte lines)
     // [cout/32][lines][k*k][4 frags][64 lanes][16 bytes]; lines = cin/64 (planes 1) or cin/32 (planes 2, 3)
-    return (size_t)(cout / 32) * (planes == 1 ? cin / 64 : cin / 32) * k * k * 4 * 64 * 16;
+    // planes 2: + cout floats, the inverse per-channel weight scales (common.h conv_wscale_inv)
+    return (size_t)(cout / 32) * (planes == 1 ? cin / 64 : cin / 32) * k * k * 4 * 64 * 16 + (planes == 2 ? (size_t)cout * sizeof(float) : 0);
 }
 
 int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
@@ -192,6 +202,28 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
                 }
         return WSI_OK;
     }
+    // planes 2 (fp16 pair, common.h PairElem): every output channel's folded weights are multiplied by a power of two that puts
+    // the channel's largest magnitude into [2^13, 2^14) - exact, and any weight within 2^-16 of the largest then has a NORMAL fp16
+    // lo part (22 significand bits), whatever the magnitude of the trained weights; the inverse scales follow the fragment
+    // blocks and the conv epilogues multiply the accumulators by them (common.h conv_wscale_inv)
+    std::vector<float> wmul(cout, 1.0f);
+    if (planes == 2) {
+        float* inv = (float*)((char*)wpk_out + (size_t)(cout / 32) * NL * NT * 4096);
+        for (int co = 0; co < cout; ++co) {
+            double sc, sh;
+            bn_fold(bn_weight, bn_bias, bn_mean, bn_var, eps, co, sc, sh);
+            float amax = 0.f;
+            for (size_t i = 0; i < (size_t)cin * k * k; ++i) amax = fmaxf(amax, fabsf((float)((double)w[(size_t)co * cin * k * k + i] * sc)));
+            int e = 0;
+            if (amax > 0.f && std::isfinite(amax)) {
+                frexpf(amax, &e);                                                  // amax = m * 2^e, m in [0.5, 1)
+                e = 14 - e;                                                        // amax * 2^e in [2^13, 2^14)
+                e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            }
+            wmul[co] = ldexpf(1.0f, e);
+            inv[co] = ldexpf(1.0f, -e);
+        }
+    }
     for (int nt = 0; nt < cout / 32; ++nt)
         for (int l = 0; l < NL; ++l)
             for (int t = 0; t < NT; ++t)
@@ -207,7 +239,8 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
                             const int ci = cbase + 8 * (lane >> 5) + j;
                             const float wf = (float)((double)w[(((size_t)co * cin + ci) * k + t / k) * k + t % k] * sc);
                             uint16_t hi, lo;
-                            split_host(wf, hi, lo);
+                            if (planes == 2) split_host_f16(wf * wmul[co], hi, lo);
+                            else split_host(wf, hi, lo);
                             frag[lane * 8 + j] = plane ? lo : hi;
                         }
                     }
@@ -216,7 +249,7 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
 }
 
 size_t wsi_prepack_stem_bytes(int planes) {
-    if (planes == 3) planes = 2;                       // mode 3 keeps the stem's own arithmetic in bf16 hi/lo
+    if (planes == 3) planes = 2;                       // mode 3 keeps the stem's own arithmetic in the split pair (fp16 hi/lo)
     return (planes < 1 || planes > 2) ? 0 : (size_t)2 * 14 * planes * 64 * 8 * 2;
 }
 
@@ -243,7 +276,8 @@ int wsi_prepack_stem(const float* w, const float* bn_weight, const float* bn_bia
                         float wf = 0.f;
                         if (kw < 7 && c < 3) wf = (float)((double)w[(((size_t)co * 3 + c) * 7 + kh) * 7 + kw] * sc);
                         uint16_t hi, lo;
-                        split_host(wf, hi, lo);
+                        if (planes == 2) split_host_f16(wf, hi, lo);     // the stem's own arithmetic in split precision: fp16 pair (r05)
+                        else split_host(wf, hi, lo);
                         frag[lane * 8 + j] = p ? lo : hi;
                     }
                 }
@@ -764,12 +798,18 @@ static int g_chunk_stem = 0, g_chunk_l1 = 0;   // sub-batch sizes (images); 0 = 
 // wsi_trunk_workspace_init), otherwise 2 * planes + (1 if stage 0 holds 96-byte lines); an unknown workspace counts as dirty.
 int g_l1_lines96 = 1;                           // A/B: wsi_conv_set_mode +16384 disables
 static std::mutex g_ws_mutex;
-static std::unordered_map<const void*, int> g_ws_layout;
-static int ws_layout_switch(const void* ws, int want) {      // returns 1 if the stage-0 buffers must be zero-filled first
+struct WsTag { int layout; size_t bytes; };                  // bytes: what wsi_trunk_workspace_init planned (0 = never initialised here)
+static std::unordered_map<const void*, WsTag> g_ws_layout;
+// returns 1 if the stage-0 buffers must be zero-filled first, 2 if everything must, -1 if the current plan (`need` bytes) exceeds
+// what the workspace was initialised for (r04 advisor finding: a workspace sized for one planes value - 2 bytes per channel at
+// planes 1 - and then run with another would be zero-filled and written past its end; the API carries no size, the tag does)
+static int ws_layout_switch(const void* ws, int want, size_t need) {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
     auto it = g_ws_layout.find(ws);
-    const int have = it == g_ws_layout.end() ? -2 : it->second;
-    g_ws_layout[ws] = want;
+    const int have = it == g_ws_layout.end() ? -2 : it->second.layout;
+    const size_t bytes = it == g_ws_layout.end() ? 0 : it->second.bytes;
+    if (bytes && need > bytes) return -1;
+    g_ws_layout[ws] = WsTag{want, bytes};
     if (have == want || have == -1) return 0;
     return (have >= 0 && have / 2 != want / 2) ? 2 : 1;      // 2: the workspace last ran another planes value - every pad may be dirty
 }
@@ -822,7 +862,7 @@ int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, v
     if (!workspace || trunk_plan(n, h, w, planes, p)) return WSI_EINVAL;
     {
         std::lock_guard<std::mutex> lk(g_ws_mutex);
-        g_ws_layout[workspace] = -1;
+        g_ws_layout[workspace] = WsTag{-1, p.total};
     }
     return hipMemsetAsync((char*)workspace + p.buf[0][0], 0, p.total - p.buf[0][0], (hipStream_t)stream) == hipSuccess
                ? WSI_OK
@@ -869,7 +909,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
     const bool l96 = g_l1_lines96 && planes == 3 && split0;
     // the tag is recorded for EVERY planes value (r03 advisor finding: a planes 1 / 2 run used to leave a stale '96-byte lines' tag,
     // and a later mx run on the same workspace then skipped the zero-fill): tag = 2 * planes + (96-byte lines)
-    if (const int dirty = ws_layout_switch(workspace, 2 * planes + (l96 ? 1 : 0))) {
+    if (const int dirty = ws_layout_switch(workspace, 2 * planes + (l96 ? 1 : 0), p.total)) {
+        if (dirty < 0) return WSI_EINVAL;              // planned for a smaller batch / another planes value than this call needs
         const size_t nbytes = dirty == 2 ? p.total - p.buf[0][0] : p.buf[0][3] - p.buf[0][0];   // the three rotating stage-0 buffers (or everything)
         if (hipMemsetAsync(ws + p.buf[0][0], 0, nbytes, st) != hipSuccess) return WSI_EFAULT;
     }

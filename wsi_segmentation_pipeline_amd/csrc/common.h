@@ -7,7 +7,7 @@
 //   out of bounds and zero where the reference zero-pads (resnets_shift.py:19-22, padding=1).
 //   Kernels never store to pad positions, so a buffer zeroed once per plan stays valid.
 //   per pixel: C*PLANES bf16, organised in 128-byte "lines":
-//     PLANES=2 (bf16x2 split, parity mode): line l = channels 32l..32l+31 as [hi x32][lo x32]
+//     PLANES=2 (fp16 pair, parity mode; r01-r04: bf16 pair): line l = channels 32l..32l+31 as [hi x32][lo x32]
 //     PLANES=1 (single bf16, speed mode)  : line l = channels 64l..64l+63
 //   A line is 8 slots of 16 bytes = 4 MFMA K-fragments f (slots 2f, 2f+1 by lane half h):
 //     PLANES=2: f = plane*2 + ks (ks = 16-wide k-step inside the 32-channel chunk)
@@ -91,7 +91,7 @@ static inline __device__ bool pf_is_pixel(const PFGeom& g, int q) {
 
 // Precision / storage modes ("planes" in the C ABI):
 //   1  bf16 single             line = 64 channels x 2 B                              (speed mode)
-//   2  bf16 hi + bf16 lo       line = 32 channels: [hi x32][lo x32]                  (3 MFMA passes)
+//   2  fp16 hi + fp16 lo       line = 32 channels: [hi x32][lo x32]                  (3 MFMA passes; PairElem below)
 //   3  fp16 hi + MX-fp6 cross  line = 32 channels: [hi fp16 x32 (64 B) | lo6 fields 0-20 (16 B) | hi6 fields 0-20 (16 B) |
 //                              lo6 rest (8 B) scale_lo (4 B) pad | hi6 rest (8 B) scale_hi (4 B) pad]
 //      x = hi + lo6*2^(scale_lo-127); the conv is  Wh*Xh (two fp16 MFMAs)  +  [Wh6*Xl6 | Wl6*Xh6] as the two K halves of ONE
@@ -181,6 +181,21 @@ static inline __device__ size_t pf_out_offset(const PFGeom& g, long long split_p
 
 static inline __device__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// 16-bit element type of the operand planes of a precision mode and its MFMA.  Mode 2 (the split-precision "parity" mode) is an
+// fp16 PAIR since r05: x ~ hi + lo with hi = fp16(x), lo = fp16(x - hi) - 22 significand bits where both are normal, an absolute
+// error of 2^-25 where lo is an fp16 subnormal (|x| < 2^-3; v_mfma_f32_32x32x16_f16 reads subnormals, tools/probes/f16_denorm.hip)
+// - against the 16 bits of the bf16 pair of r01-r04 (2^-18 relative), at the same three MFMA passes.  On the dense per-pixel path
+// the bf16 pair sat AT the 1e-3 logit contract (1.01e-3 at |logit| 16, r04); the CPU model of both pairs
+// (tests/studies/sim_seg_precision.py) puts the fp16 pair 10-20x lower.  Fragments travel as opaque 16-byte `bf16x8` values in
+// every mode; only the MFMA and the epilogue conversions know the element type.
+template <int PLANES> struct PairElem { typedef __bf16 T; };
+template <> struct PairElem<2> { typedef _Float16 T; };
+template <int PLANES>
+static inline __device__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    if constexpr (PLANES == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // mode 3 helpers ---------------------------------------------------------------------------
@@ -305,10 +320,27 @@ static __device__ __forceinline__ void pair_max2(float& x, float& y) {
 
 #endif
 
-// fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative
-static inline __device__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
-    hi = (__bf16)x;
-    lo = (__bf16)(x - (float)hi);
+// fp32 -> (hi, lo) fp16 pair of mode 2: hi + lo == clamp(x, +-65504) to 2^-22 relative / 2^-25 absolute (see PairElem)
+static inline __device__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+static inline __device__ void split_f16x4(const float* v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        _Float16 a, b;
+        split_f16(v[i], a, b);
+        hi[i] = a;
+        lo[i] = b;
+    }
+}
+// Mode-2 packed weights carry one power-of-two scale per output channel (capi.hip wsi_prepack_conv: every channel's largest
+// |weight| is moved into [2^13, 2^14), so the lo plane of every weight within 2^-16 of it is a NORMAL fp16 and weights of any
+// magnitude fit the format): the inverse scales, Cout floats, follow the fragment blocks of the pack; the epilogue multiplies
+// the accumulator by them (exact) before it adds the bias.
+static inline __device__ const float* conv_wscale_inv(const void* wpk, int cout, int cin, int ksize) {
+    return (const float*)((const char*)wpk + (size_t)(cout / 32) * (cin / 32) * ksize * ksize * 4096);
 }
 
 struct StemArgs {

@@ -308,12 +308,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
                 } else if constexpr (PLANES == 3) {
                     acc[0][mt] = mfma_mx6(acc[0][mt], w, x);
                 } else if constexpr (PLANES == 2) {
-                    acc[0][mt] = mfma_bf16(w[2], x[0], acc[0][mt]);   // lo*hi
-                    acc[0][mt] = mfma_bf16(w[3], x[1], acc[0][mt]);
-                    acc[0][mt] = mfma_bf16(w[0], x[2], acc[0][mt]);   // hi*lo
-                    acc[0][mt] = mfma_bf16(w[1], x[3], acc[0][mt]);
-                    acc[0][mt] = mfma_bf16(w[0], x[0], acc[0][mt]);   // hi*hi
-                    acc[0][mt] = mfma_bf16(w[1], x[1], acc[0][mt]);
+                    mfma_step<2>(acc[0][mt], w, x);                   // lo*hi, hi*lo, hi*hi (fp16 pair)
                 } else {
 #pragma unroll
                     for (int f = 0; f < 4; ++f) acc[0][mt] = mfma_bf16(w[f], x[f], acc[0][mt]);
@@ -978,12 +973,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
                 if constexpr (PLANES == 3) {
                     d = mfma_mx6(d, w, x);
                 } else if constexpr (PLANES == 2) {
-                    d = mfma_bf16(w[2], x[0], d);
-                    d = mfma_bf16(w[3], x[1], d);
-                    d = mfma_bf16(w[0], x[2], d);
-                    d = mfma_bf16(w[1], x[3], d);
-                    d = mfma_bf16(w[0], x[0], d);
-                    d = mfma_bf16(w[1], x[1], d);
+                    mfma_step<2>(d, w, x);
                 } else {
 #pragma unroll
                     for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);
@@ -995,6 +985,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s2_slab_kernel(ConvA
     if constexpr (FUSE) {
         ConvArgs a2 = a;
         a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
+        a2.wpk = a.wpk2; a2.ksize = 1;                        // (mode 2: the 1x1 pack's own channel scales follow ITS blocks)
         conv_epilogue_any<MT, PLANES>(a2, accd, q0 + wm * MT * 32, ntile, lane);
     }
 }
@@ -1224,6 +1215,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wide_kernel(ConvArgs a) {
         if constexpr (DS) {
             ConvArgs a2 = a;
             a2.out = a.out2; a2.bias = a.bias2; a2.resid = nullptr; a2.relu = 0;
+            a2.wpk = a.wpk2; a2.ksize = 1;                    // (mode 2: the 1x1 pack's own channel scales follow ITS blocks)
             if constexpr (PLANES == 3) conv_epilogue_mx<MT>(a2, accd[nt], qs, valid, ntile, lane);
             else conv_epilogue_q<MT, PLANES>(a2, accd[nt], qs, valid, ntile, lane);
         }

@@ -29,15 +29,22 @@ static __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rs, char
 // DMA is awaited where the kernel says so (`s_waitcnt vmcnt(0)` + barrier before the stage is read - the kernels did that
 // explicitly already).  Any vmcnt wait the compiler computes for its own loads only gets more conservative by unknown younger
 // requests (in-order completion), never unsafe.  `lds` = byte address of the wave's 1 KiB destination (wave-uniform).
+// M0: hipcc treats m0 as a reserved register - a "m0" clobber is rejected with a warning and changes nothing - while its own
+// LDS-DMA builtins (the in2 segment, the residual staging of the tails) keep m0 values alive and merge equal initialisations
+// (SIFixSGPRCopies).  So the asm leaves m0 exactly as it found it: saved to a scratch SGPR, set, used, restored (M0 is read
+// when the DMA issues; two scalar moves per transfer).
 static __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 static __device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds) {       // per-lane 64-bit source address
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds), "v"(gsrc) : "memory");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(gsrc) : "memory");
 }
 static __device__ __forceinline__ void dma16_buf_asm(__amdgpu_buffer_rsrc_t rs, unsigned lds, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
 // Residual tile (32 pixels x one 128-byte line) -> 4 KB of LDS at dst by LDS-DMA, eight lanes per line: piece
@@ -115,6 +122,8 @@ static __device__ __forceinline__ void resid_tile_dma_buf96(__amdgpu_buffer_rsrc
 template <int MT, int PLANES>
 static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                        const bool (&valid)[MT], int ntile, int lane, char* scratch = nullptr) {
+    typedef typename PairElem<PLANES>::T E;                                       // fp16 in mode 2 (fp16 pair), bf16 in mode 1
+    typedef __attribute__((ext_vector_type(4))) E Ex4;
     const int h = lane >> 5, l31 = lane & 31;
     const size_t pixstride = (size_t)a.go.C * PFmt<PLANES>::BPC;
     const size_t chan_off = (size_t)ntile * (32 * PFmt<PLANES>::BPC) + (size_t)(4 * h) * 2;
@@ -128,7 +137,7 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
     // residual: with `scratch` (8 KB of wave-private LDS, split precision) tile by tile through LDS-DMA, line-contiguous
     // (see conv_epilogue_mx); otherwise every residual load of the tile in flight at once (branch-free)
     const bool via_lds = PLANES == 2 && a.resid && scratch;
-    bf16x4 rh[MT][4], rl[MT][4];
+    Ex4 rh[MT][4], rl[MT][4];
     if (via_lds) {
         resid_tile_dma(a.resid, valid[0] ? qs[0] : a.go.G, pixstride, (size_t)ntile * 128, lane, scratch);
     } else if (a.resid) {
@@ -138,19 +147,28 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
             for (int g = 0; g < 4; ++g) {
                 const char* rp = (const char*)a.resid + poff[mt] + 16 * g;
                 if (CONV_STUDY(a, CONV_NONTEMPORAL)) {
-                    rh[mt][g] = __builtin_nontemporal_load((const bf16x4*)rp);
-                    if constexpr (PLANES == 2) rl[mt][g] = __builtin_nontemporal_load((const bf16x4*)(rp + 64));
+                    rh[mt][g] = __builtin_nontemporal_load((const Ex4*)rp);
+                    if constexpr (PLANES == 2) rl[mt][g] = __builtin_nontemporal_load((const Ex4*)(rp + 64));
                 } else {
-                    rh[mt][g] = *(const bf16x4*)rp;
-                    if constexpr (PLANES == 2) rl[mt][g] = *(const bf16x4*)(rp + 64);
+                    rh[mt][g] = *(const Ex4*)rp;
+                    if constexpr (PLANES == 2) rl[mt][g] = *(const Ex4*)(rp + 64);
                 }
             }
     }
-    float bias[16];
+    float bias[16], wsi[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[g * 4 + i] = a.bias[ntile * 32 + 8 * g + 4 * h + i];
+    if constexpr (PLANES == 2) {                                                  // per-channel inverse weight scales (common.h conv_wscale_inv)
+        const float* ws = conv_wscale_inv(a.wpk, a.go.C, a.gi.C, a.ksize) + ntile * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *(const f32x4*)(ws + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wsi[g * 4 + i] = v[i];
+        }
+    }
     // phase 2: bias + residual + ReLU, split, store
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -162,15 +180,18 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
             const int sw = (l31 >> 1) & 7;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                rh[mt][g] = *(const bf16x4*)(t + ((g ^ sw) << 4));
-                rl[mt][g] = *(const bf16x4*)(t + (((4 + g) ^ sw) << 4));
+                rh[mt][g] = *(const Ex4*)(t + ((g ^ sw) << 4));
+                rl[mt][g] = *(const Ex4*)(t + (((4 + g) ^ sw) << 4));
             }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = acc[mt][4 * g + i] + bias[4 * g + i];
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (PLANES == 2) v[i] = acc[mt][4 * g + i] * wsi[4 * g + i] + bias[4 * g + i];
+                else v[i] = acc[mt][4 * g + i] + bias[4 * g + i];
+            }
             if (a.resid) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] += (float)rh[mt][g][i];
@@ -179,24 +200,34 @@ static __device__ __forceinline__ void conv_epilogue_q(const ConvArgs& a, f32x16
                     for (int i = 0; i < 4; ++i) v[i] += (float)rl[mt][g][i];
                 }
             }
-            if (a.relu) {
+            Ex4 hi, lo;
+            if constexpr (PLANES == 2) {
+                const float lo_clamp = a.relu ? 0.f : -65504.f;                    // ReLU (if any) + fp16-range clamp in one op
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            bf16x4 hi, lo;
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = __builtin_amdgcn_fmed3f(v[i], lo_clamp, 65504.f);
+                    hi[i] = (E)v[i];
+                    lo[i] = (E)(v[i] - (float)hi[i]);
+                }
+            } else {
+                if (a.relu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hi[i] = (__bf16)v[i];
-                lo[i] = (__bf16)(v[i] - (float)hi[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hi[i] = (E)v[i];
+                    lo[i] = (E)(v[i] - (float)hi[i]);
+                }
             }
             if (valid[mt] && !CONV_STUDY(a, CONV_ABL_NO_STORE)) {
                 char* op = (char*)a.out + ooff[mt] + 16 * g;
                 if (CONV_STUDY(a, CONV_NONTEMPORAL)) {
-                    __builtin_nontemporal_store(hi, (bf16x4*)op);
-                    if constexpr (PLANES == 2) __builtin_nontemporal_store(lo, (bf16x4*)(op + 64));
+                    __builtin_nontemporal_store(hi, (Ex4*)op);
+                    if constexpr (PLANES == 2) __builtin_nontemporal_store(lo, (Ex4*)(op + 64));
                 } else {
-                    *(bf16x4*)op = hi;
-                    if constexpr (PLANES == 2) *(bf16x4*)(op + 64) = lo;
+                    *(Ex4*)op = hi;
+                    if constexpr (PLANES == 2) *(Ex4*)(op + 64) = lo;
                 }
             }
         }
@@ -423,12 +454,12 @@ static __device__ __forceinline__ void mfma_line(f32x16 (&acc)[MT], const bf16x8
             for (int f = 0; f < 4; ++f) xf[(mt + 1) & 1][f] = *(const bf16x8*)(smem + (xbase[mt + 1] ^ (f << 5)));
         }
         if constexpr (PLANES == 2) {
-            acc[mt] = mfma_bf16(wf[2], x[0], acc[mt]);   // lo*hi
-            acc[mt] = mfma_bf16(wf[3], x[1], acc[mt]);
-            acc[mt] = mfma_bf16(wf[0], x[2], acc[mt]);   // hi*lo
-            acc[mt] = mfma_bf16(wf[1], x[3], acc[mt]);
-            acc[mt] = mfma_bf16(wf[0], x[0], acc[mt]);   // hi*hi
-            acc[mt] = mfma_bf16(wf[1], x[1], acc[mt]);
+            acc[mt] = mfma16<2>(wf[2], x[0], acc[mt]);   // lo*hi
+            acc[mt] = mfma16<2>(wf[3], x[1], acc[mt]);
+            acc[mt] = mfma16<2>(wf[0], x[2], acc[mt]);   // hi*lo
+            acc[mt] = mfma16<2>(wf[1], x[3], acc[mt]);
+            acc[mt] = mfma16<2>(wf[0], x[0], acc[mt]);   // hi*hi
+            acc[mt] = mfma16<2>(wf[1], x[1], acc[mt]);
         } else {
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[mt] = mfma_bf16(wf[f], x[f], acc[mt]);
@@ -456,12 +487,12 @@ static __device__ __forceinline__ void mfma_step(f32x16& d, const bf16x8 (&w)[4]
     if constexpr (PLANES == 3) {
         d = mfma_mx6(d, w, x);
     } else if constexpr (PLANES == 2) {
-        d = mfma_bf16(w[2], x[0], d);
-        d = mfma_bf16(w[3], x[1], d);
-        d = mfma_bf16(w[0], x[2], d);
-        d = mfma_bf16(w[1], x[3], d);
-        d = mfma_bf16(w[0], x[0], d);
-        d = mfma_bf16(w[1], x[1], d);
+        d = mfma16<2>(w[2], x[0], d);
+        d = mfma16<2>(w[3], x[1], d);
+        d = mfma16<2>(w[0], x[2], d);
+        d = mfma16<2>(w[1], x[3], d);
+        d = mfma16<2>(w[0], x[0], d);
+        d = mfma16<2>(w[1], x[1], d);
     } else {
 #pragma unroll
         for (int f = 0; f < 4; ++f) d = mfma_bf16(w[f], x[f], d);

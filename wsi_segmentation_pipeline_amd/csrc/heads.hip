@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const void* in, PFGeom 
         for (int y = 0; y < g.H; ++y)
             for (int x = 0; x < g.W; ++x) {
                 const char* p = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * pixstride + coff;
-                const bf16x4 hi = *(const bf16x4*)p;
+                typedef __attribute__((ext_vector_type(4))) typename PairElem<PLANES>::T Ex4;   // mode 2: fp16 pair, 1: bf16
+                const Ex4 hi = *(const Ex4*)p;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s[k] += (float)hi[k];
                 if constexpr (PLANES == 2) {
-                    const bf16x4 lo = *(const bf16x4*)(p + 64);
+                    const Ex4 lo = *(const Ex4*)(p + 64);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) s[k] += (float)lo[k];
                 }
@@ -241,14 +242,14 @@ __global__ __launch_bounds__(256) void pf_pack_kernel(const float* in, void* out
         const int y = (int)(p % g.H);
         const int n = (int)(p / g.H);
         const float v = in[(((size_t)n * g.C + c) * g.H + y) * g.W + x];
-        __bf16 hi, lo;
-        split_bf16(v, hi, lo);
         char* o = (char*)out + (size_t)(g.G + n * g.S + y * g.P + x) * ((size_t)g.C * PLANES * 2);
-        if constexpr (PLANES == 2) {
-            *(__bf16*)(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
-            *(__bf16*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
+        if constexpr (PLANES == 2) {                                          // fp16 pair (common.h split_f16)
+            _Float16 hi, lo;
+            split_f16(v, hi, lo);
+            *(_Float16*)(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
+            *(_Float16*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
         } else {
-            *(__bf16*)(o + c * 2) = hi;
+            *(__bf16*)(o + c * 2) = (__bf16)v;
         }
     }
 }
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void pf_unpack_kernel(const void* in, float* o
         const char* o = (const char*)in + (size_t)(g.G + n * g.S + y * g.P + x) * ((size_t)g.C * PLANES * 2);
         float v;
         if constexpr (PLANES == 2)
-            v = (float)*(const __bf16*)(o + (c >> 5) * 128 + (c & 31) * 2) +
-                (float)*(const __bf16*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2);
+            v = (float)*(const _Float16*)(o + (c >> 5) * 128 + (c & 31) * 2) +
+                (float)*(const _Float16*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2);
         else
             v = (float)*(const __bf16*)(o + c * 2);
         out[(((size_t)n * g.C + c) * g.H + y) * g.W + x] = v;

@@ -66,11 +66,11 @@ static __device__ __forceinline__ void pf_line_encode(const float* v, char* line
     if constexpr (PLANES == 3) {
         mx_line_encode(v, line);
     } else if constexpr (PLANES == 2) {
-        for (int c = 0; c < 32; ++c) {
-            __bf16 hi, lo;
-            split_bf16(v[c], hi, lo);
-            ((__bf16*)line)[c] = hi;
-            ((__bf16*)(line + 64))[c] = lo;
+        for (int c = 0; c < 32; ++c) {                         // fp16 pair (common.h split_f16)
+            _Float16 hi, lo;
+            split_f16(v[c], hi, lo);
+            ((_Float16*)line)[c] = hi;
+            ((_Float16*)(line + 64))[c] = lo;
         }
     } else {
         for (int c = 0; c < 64; ++c) ((__bf16*)line)[c] = (__bf16)v[c];
@@ -79,6 +79,6 @@ static __device__ __forceinline__ void pf_line_encode(const float* v, char* line
 template <int PLANES>
 static __device__ __forceinline__ float pf_line_decode(const char* line, int chan) {
     if constexpr (PLANES == 3) return mx_line_decode(line, chan);
-    else if constexpr (PLANES == 2) return (float)((const __bf16*)line)[chan] + (float)((const __bf16*)(line + 64))[chan];
+    else if constexpr (PLANES == 2) return (float)((const _Float16*)line)[chan] + (float)((const _Float16*)(line + 64))[chan];
     else return (float)((const __bf16*)line)[chan];
 }

@@ -62,12 +62,14 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemArgs a) {
                     for (int c = 0; c < 3; ++c) v[c] = a.lut[c * 256 + px[c]];
                 }
             }
-            bf16x4 hi, lo;
+            typedef typename PairElem<PLANES>::T E;       // PLANES 2: fp16 pair (common.h), 1: bf16
+            typedef __attribute__((ext_vector_type(4))) E Ex4;
+            Ex4 hi, lo;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { hi[c] = (__bf16)v[c]; lo[c] = (__bf16)(v[c] - (float)hi[c]); }
-            hi[3] = (__bf16)0.f; lo[3] = (__bf16)0.f;
-            *(bf16x4*)(xl + (size_t)i * 8) = hi;
-            if constexpr (PLANES == 2) *(bf16x4*)(xl + STEM_PLANE_BYTES + (size_t)i * 8) = lo;
+            for (int c = 0; c < 3; ++c) { hi[c] = (E)v[c]; lo[c] = (E)(v[c] - (float)hi[c]); }
+            hi[3] = (E)0.f; lo[3] = (E)0.f;
+            *(Ex4*)(xl + (size_t)i * 8) = hi;
+            if constexpr (PLANES == 2) *(Ex4*)(xl + STEM_PLANE_BYTES + (size_t)i * 8) = lo;
         }
         __syncthreads();
 
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     if constexpr (PLANES == 2) {
-                        acc[nt][mt] = mfma_bf16(wf[nt][1], xf[mt][0], acc[nt][mt]);
-                        acc[nt][mt] = mfma_bf16(wf[nt][0], xf[mt][1], acc[nt][mt]);
+                        acc[nt][mt] = mfma16<PLANES>(wf[nt][1], xf[mt][0], acc[nt][mt]);
+                        acc[nt][mt] = mfma16<PLANES>(wf[nt][0], xf[mt][1], acc[nt][mt]);
                     }
-                    acc[nt][mt] = mfma_bf16(wf[nt][0], xf[mt][0], acc[nt][mt]);
+                    acc[nt][mt] = mfma16<PLANES>(wf[nt][0], xf[mt][0], acc[nt][mt]);
                 }
         }
         // ---- epilogue: bias + ReLU -> PF lines (a.out_pf) or f32 NHWC --------------------------
@@ -154,16 +156,15 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemArgs a) {
                     } else if (ox < Wc) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            bf16x4 hi, lo;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                hi[i] = (__bf16)v[4 * g + i];
-                                lo[i] = (__bf16)(v[4 * g + i] - (float)hi[i]);
-                            }
-                            if (a.out_planes == 2) {
-                                *(bf16x4*)(o + nt * 128 + (8 * g + 4 * h) * 2) = hi;
-                                *(bf16x4*)(o + nt * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
+                            if (a.out_planes == 2) {                             // fp16 pair (common.h split_f16)
+                                f16x4 hi, lo;
+                                split_f16x4(v + 4 * g, hi, lo);
+                                *(f16x4*)(o + nt * 128 + (8 * g + 4 * h) * 2) = hi;
+                                *(f16x4*)(o + nt * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
                             } else {
+                                bf16x4 hi;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) hi[i] = (__bf16)v[4 * g + i];
                                 *(bf16x4*)(o + (nt * 32 + 8 * g + 4 * h) * 2) = hi;
                             }
                         }
@@ -217,13 +218,16 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* in, void
         const int q = go.G + n * go.S + py * go.P + px;
         const int c = c4 * 4;
         char* o = (char*)out + (size_t)q * (64 * PLANES * 2);
-        bf16x4 hi, lo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { hi[k] = (__bf16)m[k]; lo[k] = (__bf16)(m[k] - (float)hi[k]); }
-        if constexpr (PLANES == 2) {
-            *(bf16x4*)(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
-            *(bf16x4*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
+        if constexpr (PLANES == 2) {                                              // fp16 pair (common.h split_f16)
+            f16x4 hi, lo;
+            const float mv[4] = {m[0], m[1], m[2], m[3]};
+            split_f16x4(mv, hi, lo);
+            *(f16x4*)(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
+            *(f16x4*)(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = lo;
         } else {
+            bf16x4 hi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hi[k] = (__bf16)m[k];
             *(bf16x4*)(o + c * 2) = hi;
         }
     }
@@ -250,7 +254,7 @@ constexpr int SP_COLS = 70;                  // input columns per strip (2*31 + 
 constexpr int SP_RING = 16;                  // ring rows
 constexpr int SP_PLANE = SP_RING * SP_COLS * 8;
 
-// PLANES = arithmetic of the stem itself (1: bf16, 2: bf16 hi/lo 3-pass); OUT = output line format (1, 2 or 3).
+// PLANES = arithmetic of the stem itself (1: bf16, 2: fp16 hi/lo pair, 3-pass; r01-r04: bf16 pair); OUT = output line format (1, 2 or 3).
 // U8X = DIG > 0 (u8 slide input, the product path): INTEGER arithmetic on v_mfma_i32_32x32x32_i8.  The pixel operand is the
 // exact byte quadruple (R - 128, G - 128, B - 128, inside ? 127 : 0) - 4 bytes per pixel in the LDS ring, one 16-byte
 // fragment = the four pixels (kw 4h .. 4h+3) of one kernel row, so K = 7 rows x 32 = 7 MFMA steps instead of 14.  The
@@ -372,12 +376,14 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                         for (int c = 0; c < 3; ++c) v[c] = a.lut[c * 256 + px[c]];
                     }
                 }
-                bf16x4 hi, lo;
+                typedef typename PairElem<PLANES>::T E;   // PLANES 2: fp16 pair (common.h), 1: bf16
+                typedef __attribute__((ext_vector_type(4))) E Ex4;
+                Ex4 hi, lo;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { hi[c] = (__bf16)v[c]; lo[c] = (__bf16)(v[c] - (float)hi[c]); }
-                hi[3] = (__bf16)0.f; lo[3] = (__bf16)0.f;
-                *(bf16x4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = hi;
-                if constexpr (PLANES == 2) *(bf16x4*)(smem + SP_PLANE + (size_t)(slot * SP_COLS + cc) * 8) = lo;
+                for (int c = 0; c < 3; ++c) { hi[c] = (E)v[c]; lo[c] = (E)(v[c] - (float)hi[c]); }
+                hi[3] = (E)0.f; lo[3] = (E)0.f;
+                *(Ex4*)(smem + (size_t)(slot * SP_COLS + cc) * 8) = hi;
+                if constexpr (PLANES == 2) *(Ex4*)(smem + SP_PLANE + (size_t)(slot * SP_COLS + cc) * 8) = lo;
             }
         }
     };
@@ -482,10 +488,10 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 const bf16x8 x0 = *(const bf16x8*)xp;
                 if constexpr (PLANES == 2) {
                     const bf16x8 x1 = *(const bf16x8*)(xp + SP_PLANE);
-                    acc[mt] = mfma_bf16(wreg[ks][1], x0, acc[mt]);
-                    acc[mt] = mfma_bf16(wreg[ks][0], x1, acc[mt]);
+                    acc[mt] = mfma16<PLANES>(wreg[ks][1], x0, acc[mt]);
+                    acc[mt] = mfma16<PLANES>(wreg[ks][0], x1, acc[mt]);
                 }
-                acc[mt] = mfma_bf16(wreg[ks][0], x0, acc[mt]);
+                acc[mt] = mfma16<PLANES>(wreg[ks][0], x0, acc[mt]);
             }
         }
         }
@@ -581,17 +587,16 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
             } else if (store) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    bf16x4 hi, lo;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        hi[i] = (__bf16)v[4 * g + i];
-                        lo[i] = (__bf16)(v[4 * g + i] - (float)hi[i]);
-                    }
                     const int c = wave * 32 + 8 * g + 4 * h;
-                    if constexpr (OUT == 2) {
-                        *(bf16x4*)(o + wave * 128 + (8 * g + 4 * h) * 2) = hi;
-                        *(bf16x4*)(o + wave * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
+                    if constexpr (OUT == 2) {                                        // fp16 pair (common.h split_f16)
+                        f16x4 hi, lo;
+                        split_f16x4(v + 4 * g, hi, lo);
+                        *(f16x4*)(o + wave * 128 + (8 * g + 4 * h) * 2) = hi;
+                        *(f16x4*)(o + wave * 128 + 64 + (8 * g + 4 * h) * 2) = lo;
                     } else {
+                        bf16x4 hi;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hi[i] = (__bf16)v[4 * g + i];
                         *(bf16x4*)(o + c * 2) = hi;
                     }
                 }
@@ -623,7 +628,7 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
         hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (u8x)
         hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3>), dim3((int)grid), dim3(128), lds, st, A);
-    else if (planes == 3)                             // f32 input: bf16 hi/lo arithmetic, mode-3 output lines
+    else if (planes == 3)                             // f32 input: fp16 hi/lo arithmetic, mode-3 output lines
         hipLaunchKernelGGL((stem_pool_kernel<2, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (planes == 2)
         hipLaunchKernelGGL((stem_pool_kernel<2, 2>), dim3((int)grid), dim3(128), lds, st, A);

@@ -71,7 +71,7 @@ static __device__ __forceinline__ void head_line_decode(const char* line, float 
     } else if constexpr (PLANES == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16x8 hi = __builtin_bit_cast(bf16x8, q[j]), lo = __builtin_bit_cast(bf16x8, q[4 + j]);
+            const f16x8 hi = __builtin_bit_cast(f16x8, q[j]), lo = __builtin_bit_cast(f16x8, q[4 + j]);   // fp16 pair
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[8 * j + i] = (float)hi[i] + (float)lo[i];
         }

@@ -12,7 +12,7 @@ import torch
 from . import native
 
 BN_EPS = 1e-5                                   # nn.BatchNorm2d default (reference resnets_shift.py:117)
-PARITY, SPEED, MX = 2, 1, 3                     # planes: bf16x2 split (3 passes) / single bf16 / fp16 + MX-fp6 cross terms
+PARITY, SPEED, MX = 2, 1, 3                     # planes: fp16 hi + fp16 lo pair (3 passes; r01-r04: bf16 pair) / single bf16 / fp16 + MX-fp6 cross terms
 AUTO = 'auto'                                   # AutoTrunkEngine: mx unless a stratified two-mode probe of the slide says parity
 
 
@@ -75,16 +75,17 @@ class TrunkEngine:
     """
 
     def __init__(self, state_dict, device, planes=MX, head=None, max_batch=None,
-                 mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), streams=1):
+                 mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), streams=2):
         self.lib = native.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('TrunkEngine needs a GPU device, got %s' % device)
         if planes not in (1, 2, 3):
-            raise ValueError('planes must be 1 (speed), 2 (parity, bf16 split) or 3 (mx, fp16 + MX-fp6)')
+            raise ValueError('planes must be 1 (speed), 2 (parity, fp16 pair) or 3 (mx, fp16 + MX-fp6)')
         self.planes = planes
-        # images per trunk call; None = sized so that every kernel fills the chip several times over (2000 patches of 256x256,
-        # scaled by patch area; the workspace is ~8.3 MB per 256x256 patch: 17 GB of the 288 GB)
+        # images per trunk call; None = the tuned size (6200 patches of 256 x 256, scaled by patch area: what bench.py measures) as far
+        # as the free HBM allows - the workspace is ~8.3 MB per 256 x 256 patch, one per stream slot (`_auto_cap`; r01-r04: 2000 and
+        # one stream, i.e. a caller of the drop-in modules did not get the benchmarked configuration)
         self.max_batch = None if max_batch is None else int(max_batch)
         # batches of one call are spread round-robin over `streams` HIP streams (own workspace each), so a
         # memory-bound stage of one batch overlaps an MFMA-bound stage of another and grid tails get filled
@@ -253,9 +254,26 @@ class TrunkEngine:
         return self._batched(n, lambda i, m, slot: self._run(m, ph, pw, None, slide_u8, tile_xy[i:i + m], feat, logits, fmap,
                                                              slot=slot), ph, pw)
 
+    TUNED_BATCH_256 = 6200                                   # images of 256 x 256 per trunk call (bench.py --batch default)
+
+    def _auto_cap(self, h, w):
+        """Default images per trunk call: the tuned batch scaled by patch area, limited so that the workspaces of all stream slots
+        stay inside 40 % of the memory that is free now (plus what this engine already holds)."""
+        want = max(1, int(self.TUNED_BATCH_256 * 65536 // max(h * w, 1)))
+        per = self.lib.wsi_trunk_workspace_bytes(64, h, w, self.planes) / 64.0
+        if per <= 0:
+            return want
+        try:
+            free = torch.cuda.mem_get_info(self.device)[0]
+        except Exception:
+            return want
+        held = sum(int(ws.numel()) for ws, _ in self._ws.values())
+        slots = max(1, len(self._streams))
+        return max(1, min(want, int(0.4 * (free + held) / (slots * per))))
+
     def _batched(self, n, run, h=256, w=256):
         """Split n images into max_batch chunks; with several chunks, alternate them over the side streams."""
-        cap = self.max_batch if self.max_batch else max(1, int(2000 * 65536 // max(h * w, 1)))
+        cap = self.max_batch if self.max_batch else self._auto_cap(h, w)
         sizes = batch_sizes(n, cap, h, w)
         starts = [sum(sizes[:j]) for j in range(len(sizes))]
         if len(sizes) > 1:                                  # plan every slot's workspace for the largest batch once (the last one)

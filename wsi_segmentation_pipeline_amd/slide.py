@@ -164,23 +164,76 @@ def _collective_forced():
     return os.environ.get('WSI_FORCE_COLLECTIVE') == '1' and dist.is_available() and dist.is_initialized()
 
 
+# Every collective of the path goes through ONE code path: the op list, its order, the buffer shapes and the packing are the same
+# for RCCL ("nccl": device buffers over xGMI) and gloo (CPU tests, or several ranks sharing one GPU); the ONLY difference is where
+# the wire buffer lives, and that is `_Wire.put` / `_Wire.get`.  r01-r04 wrote the two cases as separate branches, so the RCCL
+# branches - never run on more than one device - shared few lines with the tested ones.  `OP_LOG` (a list, or None) records
+# (op, shape, dtype) of every collective issued; tests/test_host_logic.py asserts the sequence.
+OP_LOG = None
+
+
+class _Wire:
+    def __init__(self, dev):
+        import torch.distributed as dist
+        self.dev = torch.device(dev)
+        self.nccl = dist.get_backend() == 'nccl'
+        self.on = self.dev if (self.nccl or self.dev.type != 'cuda') else torch.device('cpu')
+
+    def put(self, t):                                           # compute device -> wire buffer (identity under RCCL)
+        return t.to(self.on)
+
+    def get(self, t):                                           # wire buffer -> compute device (identity under RCCL)
+        return t.to(self.dev)
+
+    def new(self, shape, dtype, fill=None):
+        return torch.empty(shape, dtype=dtype, device=self.on) if fill is None else torch.full(shape, fill, dtype=dtype, device=self.on)
+
+    @staticmethod
+    def log(op, t):
+        if OP_LOG is not None:
+            OP_LOG.append((op, tuple(t.shape), str(t.dtype).replace('torch.', '')))
+
+    def all_gather(self, out, buf):
+        import torch.distributed as dist
+        self.log('all_gather', buf)
+        dist.all_gather_into_tensor(out, buf)
+        return out
+
+    def all_reduce(self, t, op):
+        import torch.distributed as dist
+        self.log('all_reduce_' + str(op).split('.')[-1].lower(), t)
+        dist.all_reduce(t, op=op)
+        return t
+
+    def broadcast(self, t, src):
+        import torch.distributed as dist
+        self.log('broadcast', t)
+        dist.broadcast(t, src)
+        return t
+
+    def p2p(self, ops):
+        """ops: [('send' | 'recv', buffer, peer)] posted together (batch_isend_irecv: concurrent xGMI links under RCCL)."""
+        import torch.distributed as dist
+        if not ops:
+            return
+        for kind, t, _ in ops:
+            self.log(kind, t)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == 'send' else dist.irecv, t, peer) for kind, t, peer in ops]):
+            q.wait()
+
+
 def gather_tile_logits(local_logits, total, rank, world):
     """Concatenate per-rank logits in rank order on every rank.  One RCCL all-gather of equal-size
     padded chunks (payload = total x C fp32: latency-bound, a single collective)."""
-    import torch.distributed as dist
     if world == 1 and not _collective_forced():
         return local_logits
+    import torch.distributed as dist
     c = local_logits.shape[1]
     chunk = (total + world - 1) // world
-    dev = local_logits.device
-    # RCCL ("nccl") gathers device buffers directly; gloo (CPU tests, or ranks sharing one GPU) goes via host memory
-    via_host = dist.get_backend() != 'nccl' and local_logits.is_cuda
-    buf = torch.zeros((chunk, c), dtype=local_logits.dtype, device='cpu' if via_host else dev)
-    buf[:local_logits.shape[0]] = local_logits
-    out = torch.empty((world * chunk, c), dtype=local_logits.dtype, device=buf.device)
-    dist.all_gather_into_tensor(out, buf)
-    if via_host:
-        out = out.to(dev)
+    wire = _Wire(local_logits.device)
+    buf = wire.new((chunk, c), local_logits.dtype, 0)
+    buf[:local_logits.shape[0]] = wire.put(local_logits)
+    out = wire.get(wire.all_gather(wire.new((world * chunk, c), local_logits.dtype), buf))
     parts = []
     for r in range(world):
         lo, hi = shard_range(total, r, world)
@@ -189,37 +242,33 @@ def gather_tile_logits(local_logits, total, rank, world):
 
 
 def allreduce_max(value, dev, world):
-    """Maximum of a host scalar over the ranks (world == 1: the value itself).  RCCL needs a device buffer, gloo a host one."""
-    import torch.distributed as dist
+    """Maximum of a host scalar over the ranks (world == 1: the value itself)."""
     if world == 1 and not _collective_forced():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    import torch.distributed as dist
+    wire = _Wire(dev)
+    t = wire.put(torch.tensor([float(value)], dtype=torch.float64))
+    return float(wire.all_reduce(t, dist.ReduceOp.MAX).item())
 
 
 def allreduce_span(span, dev):
     """Exponent span (2 int32: smallest, largest biased exponent; None = this rank added nothing) over the ranks."""
     import torch.distributed as dist
-    on = dev if dist.get_backend() == 'nccl' else 'cpu'
-    lo = (span[0:1] if span is not None else torch.full((1,), 255, dtype=torch.int32)).to(on)
-    hi = (span[1:2] if span is not None else torch.zeros(1, dtype=torch.int32)).to(on)
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    return torch.cat((lo, hi)).to(dev)
+    wire = _Wire(dev)
+    lo = wire.put(span[0:1] if span is not None else torch.full((1,), 255, dtype=torch.int32))
+    hi = wire.put(span[1:2] if span is not None else torch.zeros(1, dtype=torch.int32))
+    wire.all_reduce(lo, dist.ReduceOp.MIN)
+    wire.all_reduce(hi, dist.ReduceOp.MAX)
+    return wire.get(torch.cat((lo, hi)))
 
 
 def allreduce_map(pred):
-    """Sum a float64 prediction map over the ranks (dense 'seg' mode: each rank stitched its own tiles).  RCCL reduces device
-    buffers directly; gloo (CPU tests, or ranks sharing one GPU) goes through host memory.  Float64 sums of the fp32
-    addends are exact inside the stitch's exponent-span bound, so the result does not depend on the reduction order."""
+    """Sum a float64 prediction map over the ranks (the r02 form of the dense 'seg' exchange; gather_map_bands replaced it).
+    Float64 sums of the fp32 addends are exact inside the stitch's exponent-span bound, so the result does not depend on the
+    reduction order."""
     import torch.distributed as dist
-    if dist.get_backend() == 'nccl' or not pred.is_cuda:
-        dist.all_reduce(pred, op=dist.ReduceOp.SUM)
-        return pred
-    host = pred.cpu()
-    dist.all_reduce(host, op=dist.ReduceOp.SUM)
-    return host.to(pred.device)
+    wire = _Wire(pred.device)
+    return wire.get(wire.all_reduce(wire.put(pred), dist.ReduceOp.SUM))
 
 
 def tile_bands(txy, dy, dx, hw):
@@ -256,40 +305,29 @@ def gather_map_bands(pred, txy, dy, dx, rank, world, dst=0):
     not a copy - exact in float64 inside the stitch's exponent-span bound, so `dst` ends with the single-rank map bit for bit.
     Bytes: each rank sends its band (~1/world of the map, 200 MB / 8 at 4 x 2500^2) once; the r02 all-reduce moved the whole map
     through every rank twice.  Returns `pred`: complete on `dst`, this rank's partial map elsewhere."""
-    import torch.distributed as dist
     if world == 1:
         return pred
     C = pred.shape[0]
     rects = tile_bands(txy, dy, dx, pred.shape[1:])
-    via_host = dist.get_backend() != 'nccl' and pred.is_cuda
-    on = 'cpu' if (via_host or not pred.is_cuda) else pred.device
+    wire = _Wire(pred.device)
     # rectangle tables of every rank (a few dozen bytes): count first, then the padded tables
-    cnt = torch.tensor([len(rects)], dtype=torch.int64, device=on)
-    cnts = torch.empty(world, dtype=torch.int64, device=on)
-    dist.all_gather_into_tensor(cnts, cnt)
-    cnts = cnts.cpu().tolist()
+    cnts = wire.all_gather(wire.new((world,), torch.int64), wire.put(torch.tensor([len(rects)], dtype=torch.int64))).cpu().tolist()
     kmax = max(max(cnts), 1)
-    tab = torch.zeros((kmax, 4), dtype=torch.int64, device=on)
+    tab = torch.zeros((kmax, 4), dtype=torch.int64)
     if len(rects):
-        tab[:len(rects)] = torch.from_numpy(rects).to(on)
-    tabs = torch.empty((world * kmax, 4), dtype=torch.int64, device=on)
-    dist.all_gather_into_tensor(tabs, tab)
-    tabs = tabs.view(world, kmax, 4).cpu().numpy()
+        tab[:len(rects)] = torch.from_numpy(rects)
+    tabs = wire.all_gather(wire.new((world * kmax, 4), torch.int64), wire.put(tab)).view(world, kmax, 4).cpu().numpy()
     numel = lambda r: int(sum(C * (t[1] - t[0]) * (t[3] - t[2]) for t in tabs[r, :cnts[r]]))
     if rank != dst:
         if len(rects):
-            buf = torch.cat([pred[:, y0:y1, x0:x1].reshape(-1) for y0, y1, x0, x1 in rects.tolist()])
-            buf = buf.cpu() if via_host else buf
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst)]):
-                q.wait()
+            buf = wire.put(torch.cat([pred[:, y0:y1, x0:x1].reshape(-1) for y0, y1, x0, x1 in rects.tolist()]))
+            wire.p2p([('send', buf, dst)])
         return pred
     srcs = [r for r in range(world) if r != dst and cnts[r]]
-    bufs = {r: torch.empty(numel(r), dtype=pred.dtype, device=on) for r in srcs}
-    if srcs:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, bufs[r], r) for r in srcs]):
-            q.wait()
+    bufs = {r: wire.new((numel(r),), pred.dtype) for r in srcs}
+    wire.p2p([('recv', bufs[r], r) for r in srcs])
     for r in srcs:
-        b, off = bufs[r].to(pred.device), 0
+        b, off = wire.get(bufs[r]), 0
         for y0, y1, x0, x1 in tabs[r, :cnts[r]].tolist():
             n = C * (y1 - y0) * (x1 - x0)
             pred[:, y0:y1, x0:x1] += b[off:off + n].view(C, y1 - y0, x1 - x0)
@@ -298,14 +336,9 @@ def gather_map_bands(pred, txy, dy, dx, rank, world, dst=0):
 
 
 def broadcast_from(t, src=0):
-    """Broadcast a tensor (here: the u8 class / heat maps, 6 MB each at 2500^2) from `src`; gloo with device tensors goes via host."""
-    import torch.distributed as dist
-    if dist.get_backend() == 'nccl' or not t.is_cuda:
-        dist.broadcast(t, src)
-        return t
-    host = t.cpu()
-    dist.broadcast(host, src)
-    return host.to(t.device)
+    """Broadcast a tensor (here: the u8 class / heat maps, 6 MB each at 2500^2) from `src`."""
+    wire = _Wire(t.device)
+    return wire.get(wire.broadcast(wire.put(t), src))
 
 
 # ------------------------------------------------------------------------------ rank-resident slide regions
@@ -433,12 +466,17 @@ def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classe
         raise ValueError('local_xy must list this rank\'s %d tiles' % (hi - lo))
     xy_dev = _upload(tile_xy[lo:hi] if local_xy is None else local_xy, torch.int32, dev)
     precision = None
+    fwd_kw = {}
     if hasattr(eng, 'probe_tiles'):
-        # precision='auto': ONE mode per slide for every rank - stratified probe of this rank's shard, maximum over the ranks
-        eng.decide(allreduce_max(eng.probe_tiles(slide_level_dev, xy_dev, ph, pw), dev, world))
+        # precision='auto': ONE mode per slide for every rank - stratified probe of this rank's shard, maximum over the ranks.
+        # The probe, the decision and the forward are tied together by an explicit slide id (a token of this call), not by the
+        # identity of the tensor object: a caller's fresh view of the same level (`level[...]`, `.contiguous()`) must not make
+        # forward_tiles probe again locally and override the all-reduced decision on some ranks only (r04 advisor finding)
+        fwd_kw['slide_id'] = object()
+        eng.decide(allreduce_max(eng.probe_tiles(slide_level_dev, xy_dev, ph, pw, **fwd_kw), dev, world))
         precision = dict(eng.report)
     if hi > lo:
-        _, logits, _ = eng.forward_tiles(slide_level_dev, xy_dev, ph, pw, logits=True)
+        _, logits, _ = eng.forward_tiles(slide_level_dev, xy_dev, ph, pw, logits=True, **fwd_kw)
     else:
         logits = torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
     logits = gather_tile_logits(logits, T, rank, world)

@@ -53,6 +53,7 @@ class UNetEngine:
     """ResNet-18 encoder (TrunkEngine) + smp-style decoder on HIP kernels.  state_dict: ``encoder.*`` + ``decoder.*`` keys."""
 
     def __init__(self, state_dict, device, planes=PARITY, classes=None, max_batch=None):
+        self._ws = {}
         self.lib = native.load()
         self.device = torch.device(device)
         enc_sd = {k[len('encoder.'):]: v for k, v in state_dict.items() if k.startswith('encoder.')}
@@ -112,12 +113,24 @@ class UNetEngine:
             nbytes = self.lib.wsi_unet_workspace_bytes(C.byref(self.dw), n, h, w, self.planes)
             if nbytes == 0:
                 raise ValueError('unsupported patch shape %dx%d (need multiples of 32)' % (h, w))
-            self._ws.clear()
+            self.release_workspaces()                          # the library forgets the addresses before the allocator can reuse them
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             native.check(self.lib.wsi_unet_workspace_init(C.byref(self.dw), _ptr(ws), n, h, w, self.planes, _stream()),
                          'wsi_unet_workspace_init')
             ent = self._ws[key] = (ws, n)
         return ent
+
+    def release_workspaces(self):
+        """Free every planned workspace and make the library forget its layout tag (capi.hip g_ws_layout)."""
+        for ws, _ in self._ws.values():
+            self.lib.wsi_trunk_workspace_release(_ptr(ws))
+        self._ws.clear()
+
+    def __del__(self):
+        try:
+            self.release_workspaces()
+        except Exception:                                   # interpreter shutdown: the library may be gone
+            pass
 
     def _batch(self, h, w):
         # ~77 MB of workspace per 256x256 patch: 128 patches = 10 GB of the 288 GB
