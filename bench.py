@@ -328,11 +328,11 @@ def run_rank(args):
 
     # ------------------------------------------------------------------------------- roofline objects (rank 0's kernels)
     eff_batch = -(-per_rank_units // nb) if args.workload not in ('cfg4', 'seg') else None
-    roofline = roofline_l1 = roofline_bf16 = None
+    roofline = roofline_l1 = roofline_bf16 = roofline_stem = None
     prof_tag = os.environ.get('WSI_TRAFFIC_JSON', '')
     tj = None
     for cand in ([prof_tag] if prof_tag else []) + [os.path.join(ROOT, 'profiles', f) for f in
-                                                    ({3: ['r04_traffic_mx.json', 'r03_traffic_mx.json'], 2: ['r02_traffic.json', 'r01_traffic.json']}.get(planes, []))]:
+                                                    ({3: ['r05_traffic_mx.json', 'r04_traffic_mx.json', 'r03_traffic_mx.json'], 2: ['r02_traffic.json', 'r01_traffic.json']}.get(planes, []))]:
         if cand and os.path.exists(cand):
             tj, tpath = json.load(open(cand)), cand
             break
@@ -396,6 +396,22 @@ def run_rank(args):
                 'note': ('FETCH_SIZE of 96-byte-line reads is calibrated per pattern (tools/traffic_json.py): slab reads are tallied at x0.972 of '
                          'their bytes, the residual tile reads at x0.5') if traffic_l1 else
                         'FETCH_SIZE uncalibrated for 96-byte-line reads (x1.03 .. x2): no total; algorithmic reads are 59 % of the algorithmic bytes'}
+
+    # stem (tile read + transform + conv7x7 + BN + ReLU + maxpool, one launch per batch): HBM-side roofline.  Algorithmic bytes per tile =
+    # the tile's u8 pixels in (256 x 256 x 3) + the pooled 64 x 64 x 64 map out (3 bytes per channel in mx's 96-byte lines, 4 in 128-byte
+    # lines, 2 in single-pass bf16).  The kernel is VALU-bound: the PMC read-out says how far from the byte floor.
+    roofline_stem = None
+    st_k = per_kind.get('stem_maxpool')
+    if st_k and eff_batch:
+        lines96_s = planes == MX and not (args.s2 >= 0 and args.s2 & 16384)
+        alg_s = eff_batch * (TILE * TILE * 3 + 64 * 64 * 64 * (3 if lines96_s else 2 if planes == 1 else 4))
+        gbs_s = alg_s / (st_k['avg_ms'] * 1e-3) / 1e9
+        roofline_stem = {'kernel': 'stem_pool_kernel (1 launch per batch: u8 tile read + ToTensor / Normalize folded into integer weights + conv7x7 s2 + BN + ReLU + maxpool 3x3 s2)',
+                         'bound': 'hbm', 'achieved': round(gbs_s, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs_s / PEAK_HBM_GBS, 4),
+                         'traffic': pmc_bytes('stem_pool', eff_batch), 'algorithmic_bytes_per_launch': round(alg_s),
+                         'avg_launch_ms': round(st_k['avg_ms'], 4), 'share_of_step': st_k['share_of_step'],
+                         'limiter': 'VALU: ~10 vector instructions per i8 MFMA, matrix pipe ~0.43 busy (profiles/r05_pmc/trunk_kernels_counters.txt); '
+                                    'times over the byte floor at the achievable 6.3 TB/s: %.1f' % (st_k['avg_ms'] * 1e-3 / (alg_s / 6.3e12))}
 
     # the same dominant kernel in single-pass bf16 (the literal dtype of BASELINE configs[1]; logit error ~2e-2, outside the
     # contract, so never the headline): one profiled pass on rank 0, outside the timed region
@@ -516,7 +532,7 @@ def run_rank(args):
             ma.scan_level, ma.scan_resize, ma.num_classes, ma.class_probs = 0, 1, 4, [0., 0., 0., 0.]
             ma.tile_w = ma.tile_h = ma.tile_stride_w = ma.tile_stride_h = TILE
             ma.wsi_mask_pth, ma.val_save_pth = td, os.path.join(td, 'out')
-            Image.fromarray(np.full(map_hw, 255, np.uint8)).save(os.path.join(td, 'bench.svs.png'))     # "no mask": everything is foreground
+            Image.fromarray(np.ones(map_hw, np.uint8)).save(os.path.join(td, 'bench.svs.png'))          # "no mask": everything is foreground (0 / 1, as find_nuclei returns it)
 
             def make_dataset():
                 sl = S.ArraySlide([full, np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8)], [1.0, 4.0, 16.0])
@@ -623,7 +639,7 @@ def run_rank(args):
             'data': 'synthetic (seeded u8 slide resident in HBM, seeded random ResNet-18 weights)',
             'config': {'workload': workload_desc, 'tiles_total': tiles_total, 'batch': args.batch, 'mode': args.mode,
                        'parallelism': parallelism, 'batches_in_flight': max(1, args.streams)},
-            'roofline': roofline, 'roofline_layer1': roofline_l1, 'roofline_bf16': roofline_bf16, 'cpu_baseline': cpu_baseline,
+            'roofline': roofline, 'roofline_layer1': roofline_l1, 'roofline_stem': roofline_stem, 'roofline_bf16': roofline_bf16, 'cpu_baseline': cpu_baseline,
             'contract': contract, 'parity': parity_leg, 'api': api,
             'kernels': per_kind,
             'kernel_leg': ({'ms_per_step': round(prof_dt / args.steps * 1e3, 3), 'steps': args.steps, 'batches_in_flight': 1,

@@ -381,3 +381,28 @@ def test_256_cout_stride2_workgroups_are_bit_identical(dev, sd):
                 assert torch.equal(a, b), t
         finally:
             lib.wsi_conv_set_mode(1)
+
+
+def test_eight_pixel_slab_rows_are_bit_identical(dev, sd):
+    """conv3x3s1_wide_kernel<.., D8> (r05: on 8 x 8 maps the LDS slab keeps rows of eight pixels - no pad column - and edge lanes
+    read zero pixels, which removes the bank conflicts of the 9-pixel pitch) multiplies the same operands in the same order as the
+    padded-flat slab image (wsi_conv_set_mode + 131072): identical bits in all three precision modes, on batches that fill whole
+    256-pixel tiles (8 tiles = 2 tiles of four images), a ragged last tile (9, 3, 1 images) and through the extra K segment of the
+    strided block (layer4.0.conv2 carries the folded 1x1 downsample in mx)."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    g = torch.Generator(device=dev).manual_seed(29)
+    for planes in (3, 2, 1):
+        eng = TrunkEngine(sd, dev, planes=planes, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=16)
+        for n in (8, 9, 3, 1):
+            slide = torch.randint(0, 256, (256 * 3, 256 * 3, 3), dtype=torch.uint8, device=dev, generator=g)
+            xy = torch.tensor([[256 * (i % 3), 256 * (i // 3)] for i in range(n)], dtype=torch.int32, device=dev)
+            new = [v.clone() for v in eng.forward_tiles(slide, xy, 256, 256, feat=True, logits=True, fmap=True)]
+            try:
+                native.check(lib.wsi_conv_set_mode(1 + 131072), 'conv mode')
+                old = eng.forward_tiles(slide, xy, 256, 256, feat=True, logits=True, fmap=True)
+                for a, b in zip(new, old):
+                    assert torch.equal(a, b), (planes, n)
+            finally:
+                lib.wsi_conv_set_mode(1)

@@ -588,10 +588,22 @@ static int launch_rows(const ConvArgs& a, hipStream_t st) {
 // main loop, so vmcnt only ever tracks DMA.
 // General shape: WM x WN waves, each MT = 4 pixel tiles x NT channel tiles; the default (2, 2, 2) is the 256 px x 128
 // couts form above, (4, 2, 1) = 512 px x 64 couts serves the 64-channel layer 1 (four waves share each weight stage).
-template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
+// D8 (r05; 8 x 8 maps = the trunk's layer 4 at 256 x 256 patches, BM = 256 = four whole images): the slab image in LDS has rows of
+// EIGHT pixels - the pad column of the padded-flat layout is not copied - so the 16 lanes the hardware serves together on a
+// ds_read_b128 (two map rows of a dense tile, conv_dev.h dense_lane_pixel) are 16 CONSECUTIVE slab pixels for every tap and hit 16
+// different bank groups.  With the 9-pixel pitch of the r01-r04 image every such group held two pixels that are equal modulo 16
+// (residues 0 and 2 occur three times in a 32-pixel tile: no lane order avoids it) - 40 % of the layer-4 launches' LDS cycles were
+// conflict cycles (profiles/r04_pmc).  Rows still follow each other as in memory (image rows, then the zero row two images share),
+// so one DMA round of 32 slab pixels = 4 rows = 36 memory pixels: per-lane offset + scalar offset per round, as before.  What the pad
+// column gave for free - zeros left of x = 0 and right of x = 7 - becomes a redirect: a lane whose tap falls outside its row reads
+// one of 16 zero pixels behind the slab, the one with the residue (mod 16) of the pixel it would have read, which keeps the group
+// conflict-free (3 vector instructions on six of the nine taps).
+template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2, bool D8 = false>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MT = 4, BM = WM * 128, NTHREADS = WM * WN * 64, NTILES = WN * NT, WB = NTILES * 4096;
+    constexpr int D8_ZB = 304;                                // D8: first of the 16 zero pixels (37 rows of 8 = 296 slab pixels, next multiple of 16)
+    static_assert(!D8 || (BM == 256 && NTHREADS == 256), "D8: four whole 8 x 8 images per tile, 32 slab pixels per DMA round");
     constexpr int RESID_NBUF = 4;                             // residual tiles in flight per wave (mode 3; launch_wide sizes the LDS)
     char* const wl = smem;                                    // 2 weight buffers of NTILES x 4 KB
     char* const xl = smem + 2 * WB;                           // pixel slab
@@ -615,19 +627,36 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     bool valid[MT];                                           // xoff + slab0 + P + 1 (rebuilt after the main loop: four registers less in it)
     int slab0, npieces;
     const int lpix = a.gi.W < 32 ? dense_lane_pixel(l31) : l31;      // bank-conflict-free lane order on narrow maps (conv_dev.h)
-    {
-        const int HW = a.gi.H * a.gi.W, R = a.gi.N * HW;
+    const int Rtot = a.gi.N * a.gi.H * a.gi.W;
+    if constexpr (D8) {
+        // slab row r = memory row (image n0, y = -1) + r; pixel (n, y, x) of the tile sits at slab pixel 8 (1 + 9 (n - n0) + y) + x, so
+        // tap (ty, tx) of it is slab pixel xoff + 8 ty + tx with xoff = 8 (9 (n - n0) + y) + x - 1
+        const int i0 = mtile * BM, i1 = min(i0 + BM, Rtot) - 1, n0 = i0 >> 6;
+        slab0 = a.gi.G + n0 * a.gi.S - P;                     // memory pixel of (n0, -1, 0): the zero row in front of the image (or the guard)
+        npieces = (1 + 9 * ((i1 >> 6) - n0 + 1)) * 64;       // rows x 8 pixels x 8 pieces
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int i = i0 + wm * MT * 32 + mt * 32 + lpix;
+            valid[mt] = i < Rtot;
+            const int ii = valid[mt] ? i : i1;
+            xoff[mt] = 8 * (9 * ((ii >> 6) - n0) + ((ii >> 3) & 7)) + (ii & 7) - 1;
+        }
+    } else {
         auto pos = [&](int i) { return pf_pos_of_index(a.gi, i); };
-        const int i0 = mtile * BM, i1 = min(i0 + BM, R) - 1;
+        const int i0 = mtile * BM, i1 = min(i0 + BM, Rtot) - 1;
         slab0 = pos(i0) - P - 1;
         npieces = (pos(i1) + P + 1 - slab0 + 1) * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int i = i0 + wm * MT * 32 + mt * 32 + lpix;
-            valid[mt] = i < R;
+            valid[mt] = i < Rtot;
             xoff[mt] = pos(valid[mt] ? i : i1) - slab0 - (P + 1);
         }
     }
+    // D8: lanes in map column 0 / 7 read a zero pixel on the taps that leave their row (the tile's 32 pixels are four whole rows:
+    // the column is the same for every tile of the lane)
+    const bool d8_left = D8 && (lpix & 7) == 0, d8_right = D8 && (lpix & 7) == 7;
+    constexpr int RPIX = D8 ? 36 : NTHREADS / 8;              // memory pixels one DMA round advances
     // slab DMA by buffer addressing (see conv3x3s1_slab3_kernel): one per-lane byte offset, scalar offsets per line / round
     static_assert((NTHREADS / 8) % 16 == 0, "whole swizzle periods per DMA round");
     const size_t slab_byte0 = (size_t)slab0 * in_pixstride;
@@ -637,7 +666,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     int xvoff;
     {
         const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
-        xvoff = Pl * (int)in_pixstride + sl * 16;
+        xvoff = (D8 ? (Pl >> 3) * 9 + (Pl & 7) : Pl) * (int)in_pixstride + sl * 16;
+    }
+    if constexpr (D8) {                                       // the 16 zero pixels (2 KB; the first line's barrier publishes them)
+        if (tid < 128) *(u32x4*)(xl + D8_ZB * 128 + tid * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     // weights of (line c, tap t) for the workgroup's NTILES channel tiles -> buffer wb: 256 pieces of 16 B per tile.  Main-loop DMA
     // (weights one tap ahead, slab) goes through dma16_buf_asm: a pending LDS-DMA *builtin* makes hipcc wait lgkmcnt(0) before
@@ -667,8 +699,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         }
     }
 
-    auto xload = [&](bf16x8(&x)[4], int Pl) {
+    auto xload = [&](bf16x8(&x)[4], int Pl, int tx = 1) {     // tx: the tap's column (D8: 0 / 2 leave the row on the edge lanes)
         asm volatile("" : "+v"(Pl));                          // opaque: each step's address arithmetic stays at the step (no hoisting, no spills)
+        if constexpr (D8) {
+            if (tx == 0) Pl = d8_left ? D8_ZB + (Pl & 15) : Pl;
+            if (tx == 2) Pl = d8_right ? D8_ZB + (Pl & 15) : Pl;
+        }
         const int base = lds_xbase(Pl, h);
 #pragma unroll
         for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
@@ -685,15 +721,15 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
         WSTAMP(st_a = __builtin_readcyclecounter();)
         if (c) __syncthreads();                               // slab and weight buffers are free again
         for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-            dma16_buf_asm(xrs, xl_addr + i0 * 16, xvoff, c * 128 + r * (NTHREADS / 8) * (int)in_pixstride);
+            dma16_buf_asm(xrs, xl_addr + i0 * 16, xvoff, c * 128 + r * RPIX * (int)in_pixstride);
         wdma(c, 0, kpar * WB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a;)
-        int Pc = P;
+        int Pc = D8 ? 8 : P;                                  // slab pitch
         asm volatile("" : "+s"(Pc));
         bf16x8 xf[2][4], wf[NT][4];
-        xload(xf[0], xoff[0]);
+        xload(xf[0], xoff[0], 0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const char* wb = wl + kpar * WB;
@@ -706,8 +742,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
             for (int mt = 0; mt < MT; ++mt) {
                 const int k = t * MT + mt;
                 if constexpr (!(ABL & 32)) {
-                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff);
-                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next);
+                    if (mt + 1 < MT) xload(xf[(k + 1) & 1], xoff[mt + 1] + toff, t % 3);
+                    else if (t < 8) xload(xf[(k + 1) & 1], xoff[0] + toff_next, (t + 1) % 3);
                 }
                 __builtin_amdgcn_sched_barrier(0);            // next pixel fragments requested before this tile's MFMAs
                 const bf16x8(&x)[4] = xf[k & 1];
@@ -728,7 +764,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
     WSTAMP(const unsigned long long st_loop_end = __builtin_readcyclecounter();)
     int qs[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) qs[mt] = xoff[mt] + slab0 + (P + 1);
+    for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (D8) {                                   // PF position of the lane's pixel (rows past the end repeat the tile's last pixel)
+            const int i = mtile * BM + wm * MT * 32 + mt * 32 + lpix;
+            qs[mt] = pf_pos_of_index(a.gi, valid[mt] ? i : min(mtile * BM + BM, Rtot) - 1);
+        } else {
+            qs[mt] = xoff[mt] + slab0 + (P + 1);
+        }
+    }
     if constexpr (PLANES == 3) {
         if (a.in2) {
             // Extra K segment (common.h ConvArgs.in2): the strided block's 1x1 downsample of the block input, one centre tap per
@@ -742,7 +785,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
             int xvoff2;
             {
                 const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
-                xvoff2 = Pl * (int)ps2 + sl * 16;
+                xvoff2 = (D8 ? (Pl >> 3) * 9 + (Pl & 7) : Pl) * (int)ps2 + sl * 16;
             }
             const char* wsrc2 = (const char*)a.wpk2 + (size_t)(nb * NTILES) * NC2 * 4096 + (size_t)(tid & 255) * 16;
 #pragma unroll
@@ -757,7 +800,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
             for (int c = 0; c < NC2; ++c) {
                 __syncthreads();                              // slab and weight buffers are free again
                 for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-                    dma16_buf(xrs2, xl + (size_t)i0 * 16, xvoff2, c * 128 + r * (NTHREADS / 8) * (int)ps2);
+                    dma16_buf(xrs2, xl + (size_t)i0 * 16, xvoff2, c * 128 + r * RPIX * (int)ps2);
 #pragma unroll
                 for (int p0 = 0; p0 < NTILES * 256; p0 += NTHREADS) {
                     const int pw = p0 + wave * 64;
@@ -771,7 +814,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     bf16x8 x2[4];
-                    xload(x2, xoff[mt] + P + 1);              // the centre tap
+                    xload(x2, xoff[mt] + (D8 ? 8 : P) + 1);   // the centre tap
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mfma_step<PLANES>(acc[nt][mt], wf2[nt], x2);
                 }
@@ -804,19 +847,24 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_wide_kernel(ConvA
 }
 
 
-template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2>
+int g_wide_d8 = 1;                                       // A/B (wsi_conv_set_mode +131072 off): 8-pixel slab rows on 8 x 8 maps (r05)
+template <int PLANES, int MINW, int ABL = 0, int WM = 2, int WN = 2, int NT = 2, bool D8 = false>
 static int launch_wide(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = WM * 128, NTHREADS = WM * WN * 64, BN = WN * NT * 32;
     if (a.go.C % BN) return WSI_EINVAL;
+    if constexpr (!D8 && ABL == 0 && WM == 2 && WN == 2 && NT == 2) {
+        if (g_wide_d8 && a.gi.W == 8 && a.gi.H == 8) return launch_wide<PLANES, MINW, 0, 2, 2, 2, true>(a, st);
+    }
     const int nblocks = a.go.C / BN;
     const long long R = (long long)a.gi.N * a.gi.H * a.gi.W;
     const int mtiles = (int)((R + BM - 1) / BM);
-    size_t xbytes = (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
+    size_t xbytes = D8 ? (size_t)(304 + 16) * 128       // 37 rows of 8 pixels (rounded to 16) + the 16 zero pixels
+                       : (size_t)((dense_max_slab_pixels(a, BM) * 8 + NTHREADS - 1) / NTHREADS * NTHREADS) * 16;
     if (xbytes < (size_t)WM * WN * 8192) xbytes = (size_t)WM * WN * 8192;    // residual staging of the epilogue (mode 2: in the slab)
     size_t lds = 2 * (BN / 32) * 4096 + xbytes;
     if (PLANES == 3 && lds < (size_t)WM * WN * 4 * 4096) lds = (size_t)WM * WN * 4 * 4096;   // mode 3: four residual tiles per wave, from smem + 0
     if (lds > 160 * 1024) return WSI_EINVAL;
-    auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT>;
+    auto k = conv3x3s1_wide_kernel<PLANES, MINW, ABL, WM, WN, NT, D8>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return WSI_EINVAL;
     const int grid = (a.flags & CONV_XCD_RANGES) ? (mtiles * nblocks + 7) / 8 * 8 : mtiles * nblocks;

@@ -263,8 +263,8 @@ class TrunkEngine:
         per = self.lib.wsi_trunk_workspace_bytes(64, h, w, self.planes) / 64.0
         if per <= 0:
             return want
-        try:
-            free = torch.cuda.mem_get_info(self.device)[0]
+        try:                                                 # free = what the driver reports + what torch's caching allocator holds unused
+            free = torch.cuda.mem_get_info(self.device)[0] + max(0, torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
         except Exception:
             return want
         held = sum(int(ws.numel()) for ws, _ in self._ws.values())
