@@ -406,3 +406,26 @@ def test_eight_pixel_slab_rows_are_bit_identical(dev, sd):
                     assert torch.equal(a, b), (planes, n)
             finally:
                 lib.wsi_conv_set_mode(1)
+
+
+def test_persistent_layer1_kernel_is_bit_identical(dev, sd):
+    """conv3x3s1_l1p_kernel (r05: one persistent workgroup per CU, a producer wave issues every LDS-DMA one unit ahead, residual tiles
+    staged in a 96-byte pitch) multiplies and sums exactly as conv3x3s1_rows_kernel (wsi_conv_set_mode + 1048576): identical bits on
+    batches that give every workgroup several tiles (40 tiles = 640 layer-1 tiles on 256 workgroups), fewer tiles than workgroups
+    (1, 3, 9 tiles) and a ragged split over the eight XCD ranges (17)."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.engine import TrunkEngine
+    lib = native.load()
+    g = torch.Generator(device=dev).manual_seed(31)
+    eng = TrunkEngine(sd, dev, planes=3, head=(sd['fc0.weight'], sd['fc0.bias']), max_batch=64)
+    slide = torch.randint(0, 256, (256 * 7, 256 * 6, 3), dtype=torch.uint8, device=dev, generator=g)
+    for n in (40, 17, 9, 3, 1):
+        xy = torch.tensor([[256 * (i % 6), 256 * (i // 6)] for i in range(n)], dtype=torch.int32, device=dev)
+        new = [v.clone() for v in eng.forward_tiles(slide, xy, 256, 256, feat=True, logits=True, fmap=True)]
+        try:
+            native.check(lib.wsi_conv_set_mode(1 + 1048576), 'conv mode')
+            old = eng.forward_tiles(slide, xy, 256, 256, feat=True, logits=True, fmap=True)
+            for a, b in zip(new, old):
+                assert torch.equal(a, b), n
+        finally:
+            lib.wsi_conv_set_mode(1)

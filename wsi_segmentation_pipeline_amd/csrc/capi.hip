@@ -537,7 +537,7 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
 }
 
 extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_ranges, g_slab_pair;
-extern int g_l1_lines96, g_s2_nt4, g_l1_rows, g_wide_d8;
+extern int g_l1_lines96, g_s2_nt4, g_l1_rows, g_wide_d8, g_l1p;
 extern int g_unet_fuse_up;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
@@ -547,7 +547,8 @@ int wsi_conv_set_mode(int s2_slab) {
     g_unet_fuse_up = (s2_slab & 65536) ? 0 : 1;
     g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_s2_nt4 = (s2_slab & 32768) ? 0 : 1;
-    g_wide_d8 = (s2_slab & 131072) ? 0 : 1;              // A/B: 8-pixel slab rows of the wide kernel on 8 x 8 maps (r05)
+    g_wide_d8 = (s2_slab & 131072) ? 0 : 1;
+    g_l1p = (s2_slab & 1048576) ? 1 : 0;                  // A/B: persistent producer-fed layer-1 kernel (conv.hip conv3x3s1_l1p_kernel, r05)              // A/B: 8-pixel slab rows of the wide kernel on 8 x 8 maps (r05)
     g_xcd_ranges = (s2_slab & 256) ? 0 : (s2_slab & 512) ? 1 : 2;          // +256: off, +512: 64-channel layer only
     g_s2_ablate = (s2_slab & 64) ? 1 : 0;                 // bottleneck study only: stride-2 kernel without weight loads (wrong results)
     g_xcd_order = (s2_slab & 8) ? 1 : 0;

@@ -578,6 +578,261 @@ static int launch_rows(const ConvArgs& a, hipStream_t st) {
 
 
 // --------------------------------------------------------------------------------------------
+// Persistent, producer-fed form of the row-stacked kernel (r05; mode 3, 64-wide maps with 96-byte lines, 64 output channels: the
+// trunk's layer 1).  Why: the r04 stamps and the r05 residual / no-residual comparison show conv3x3s1_rows_kernel bound by how many
+// bytes a CU keeps in flight, not by a pipe - each of its three workgroups per CU runs [slab load][multiply][slab load][multiply]
+// [residual round trips + encode] strictly one after the other, the three time-slice the matrix pipe (which triples the time every
+// slab occupies the LDS), and 160 KB of LDS cannot hold a second slab per workgroup: ~24 KB in flight per CU, 3.0 TB/s.  Here ONE
+// workgroup per CU walks its share of the tiles: four compute waves (2 column halves x 2 channel tiles, four map rows each, exactly
+// the rows kernel's multiply loop) and one PRODUCER wave that issues every LDS-DMA of the workgroup - the slab of the next
+// (tile, line) unit into the second slab buffer and, on a tile's last line, the sixteen residual tiles - one unit ahead of their
+// use.  The compute waves issue no DMA, so their in-order vmcnt only ever tracks their own weight fetches and stores (a DMA issued
+// by a compute wave would sit in front of every later weight load: the wave would wait for the slab before it may use the
+// weights); the producer waits vmcnt(0) and the unit's barrier publishes what landed.  Per unit two barriers:
+//   B1: slab u + 1 (and the tile's residual tiles) have landed, every compute wave is done with slab u
+//       -> the producer requests slab u + 2 into the buffer of slab u; all five waves rebuild the hi6 plane of slab u + 1
+//   B2: slab u + 1 is complete -> on a tile's last line the compute waves add the residual (identity MFMA), encode and store
+// Residual tiles are staged in a 96-byte pitch (six stored slots per pixel; the identity step never reads the hi6 plane), 48 KB for
+// the 16 tiles of a workgroup: LDS = 2 x 49 KB + 48 KB.  Same operands in the same order as conv3x3s1_rows_kernel: identical bits.
+// Requires at least two input lines per tile (the staging area of tile k is refilled one unit before tile k + 1 ends).
+constexpr int L1P_SLAB_PIX = 392;                             // 5 P + 66 = 391 slab pixels at P = 65, rounded to whole 16-byte slots of 8
+constexpr int L1P_SLAB = L1P_SLAB_PIX * 128;
+constexpr int L1P_STAGE = 16 * 3072;                          // sixteen residual tiles of 32 pixels x 96 bytes
+constexpr int L1P_LDS = 2 * L1P_SLAB + L1P_STAGE;
+template <int NCT>
+__global__ __launch_bounds__(320, 1) void conv3x3s1_l1p_kernel(ConvArgs a) {
+    static_assert(NCT >= 2 && NCT % 2 == 0, "the slab buffer of a unit is its line's parity; the staging area needs two lines per tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, P = 65, NPIX = 391;
+    char* const stage = smem + 2 * L1P_SLAB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave == 4;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;            // compute waves: column half of the 64-wide map, channel tile
+    const int l31 = lane & 31, h = lane >> 5;
+    constexpr int NC = NCT;                                   // input lines (the line loop is unrolled: accumulators live inside one tile iteration)
+    const int in_pixstride = a.gi.C * 3;                      // 96-byte lines
+    // this workgroup's tiles: XCD x (= id & 7) owns a contiguous range of tiles, its workgroups take them round-robin, so the tiles in
+    // flight on one XCD are neighbours (they share halo rows in that XCD's L2)
+    const int mtiles = (a.gi.N * a.gi.H * a.gi.W) >> 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int chunk = (mtiles + 7) >> 3;
+    const int t_lo = xcd * chunk, t_hi = min(t_lo + chunk, mtiles);
+    const int ntl = t_hi - t_lo > slot ? (t_hi - t_lo - slot + per - 1) / per : 0;
+    const int nunits = ntl * NC;
+    if (nunits == 0) return;                                  // (uniform: the whole workgroup leaves)
+    auto tile_p0 = [&](int k) { return pf_pos_of_index(a.gi, (t_lo + slot + k * per) << 8); };   // first pixel of the tile's first row
+
+    // ---- producer: per-lane constants of its DMA patterns ----
+    // slab: instruction r moves pieces 64 r .. 64 r + 63 = slab pixels 8 r .. 8 r + 7; the swizzle key ((Pl >> 1) & 7) of pixel
+    // Pl = 8 r + (lane >> 3) depends on the parity of r: two per-lane offsets / activity masks
+    int sv[2];
+    bool sact[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int Pl = 8 * par + (lane >> 3), sl = (lane & 7) ^ ((Pl >> 1) & 7);
+        sv[par] = (lane >> 3) * in_pixstride + mx96_piece(sl) * 16;
+        sact[par] = mx96_stored(sl);
+    }
+    // residual tile: 192 pieces (32 pixels x 6 stored slots, 96-byte pitch in the staging area) in three instructions
+    const int r_pixstride = a.go.C * 3;
+    int rv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int g = 64 * k + lane;
+        rv[k] = (g / 6) * r_pixstride + (g % 6) * 16;
+    }
+    auto dma_slab = [&](int u) {                              // unit u -> slab buffer u & 1
+        const int k = u / NC, c = u - k * NC;
+        const size_t byte0 = (size_t)(tile_p0(k) - P - 1) * in_pixstride;
+        const size_t in_bytes = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * in_pixstride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + byte0), 0,
+                                                                             (int)min(in_bytes - byte0, (size_t)0x7fffffff), 0x00020000);
+        const unsigned dst = lds_addr_of(smem + (u & 1) * L1P_SLAB);
+        for (int r = 0; r < (NPIX * 8 + 63) / 64; ++r) {
+            const bool on = sact[r & 1] && (r * 64 + lane) < NPIX * 8;
+            if (on) dma16_buf_asm(rs, dst + r * 1024, sv[r & 1], c * 96 + r * 8 * in_pixstride);
+        }
+    };
+    auto dma_resid = [&](int k) {                             // the sixteen residual tiles of tile k -> staging area
+        const int p0 = tile_p0(k);
+        const size_t byte0 = (size_t)p0 * r_pixstride;
+        const size_t r_bytes = (size_t)pf_alloc_pixels(a.go.N, a.go.H, a.go.W) * r_pixstride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.resid + byte0), 0,
+                                                                             (int)min(r_bytes - byte0, (size_t)0x7fffffff), 0x00020000);
+        for (int w = 0; w < 4; ++w)
+            for (int mt = 0; mt < MT; ++mt) {
+                const int soff = (mt * P + (w >> 1) * 32) * r_pixstride + (w & 1) * 96;      // tile (wave w, row mt): pixels p0 + mt P + 32 wm + 0..31, line wn
+                const unsigned dst = lds_addr_of(stage + (w * MT + mt) * 3072);
+#pragma unroll
+                for (int k3 = 0; k3 < 3; ++k3) dma16_buf_asm(rs, dst + k3 * 1024, rv[k3], soff);
+            }
+    };
+    auto barrier = [&]() {                                    // raw barrier: LDS traffic of this wave is complete, nothing else is drained
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- compute waves: weights, accumulators ----
+    const int ntile = wn;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wpk + (size_t)ntile * NC * 9 * 4096), 0, NC * 9 * 4096, 0x00020000);
+    const int wvoff = lane * 16;
+    f32x16 acc[1][MT];
+    bf16x8 wbuf[3][4], xf[2][4];
+    auto wload = [&](bf16x8(&w)[4], int soff) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            w[f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, soff + f * 1024, 0));
+    };
+    const int xoff0 = wm * 32 + l31;                          // slab-local pixel of tap (0, 0) of tile row 0
+
+    // ---- prologue: slab 0 (and slab 1) ----
+    if (producer) {
+        dma_slab(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    barrier();
+    if (producer && nunits > 1) dma_slab(1);
+    mx96_rebuild_hi6(smem, NPIX, tid, 320);
+    barrier();
+
+    for (int k = 0; k < ntl; ++k) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int u = k * NC + c;
+        const bool last_line = c == NC - 1;
+        if (producer) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab u + 1 (and this tile's residual tiles) have landed
+        } else {
+            const char* const xl = smem + (c & 1) * L1P_SLAB;
+            auto xload = [&](bf16x8(&x)[4], int Pl) {
+                asm volatile("" : "+v"(Pl));                  // opaque: each set's address arithmetic stays at the set
+                const int base = lds_xbase(Pl, h);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) x[f] = *(const bf16x8*)(xl + (base ^ (f << 5)));
+            };
+            if (c == 0) acc_init_bias<MT>(acc[0], a.bias, ntile, lane);
+            // the line's first column of weights is requested HERE, after the barriers: kept in flight across the barriers, the hi6
+            // rebuild or the tail (r05 compile experiments: prefetch from the previous unit's last column, from the start of the tail,
+            // from before the rebuild) the ring's 48 registers make hipcc spill weight fragments INSIDE the multiply loops (316-448
+            // bytes of scratch at 256 registers; this form: 116 bytes, all in the tail)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) wload(wbuf[dy], (c * 9 + dy * 3) * 4096);
+            int Pc = P;
+            asm volatile("" : "+s"(Pc));
+            const int sline = c * 9 * 4096;
+            xload(xf[0], xoff0);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int kk = dx * 6 + j;
+                    if (j < 5) xload(xf[(kk + 1) & 1], xoff0 + (j + 1) * Pc + dx);
+                    else if (dx < 2) xload(xf[(kk + 1) & 1], xoff0 + dx + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int dy = j - mt;
+                        if (dy >= 0 && dy < 3) acc[0][mt] = mfma_mx6(acc[0][mt], wbuf[dy], xf[kk & 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // slot j - 3 has seen its last step of this column: the next column's tap
+                    if (j >= 3 && dx < 2) {
+                        wload(wbuf[j - 3], sline + ((j - 3) * 3 + dx + 1) * 4096);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        barrier();                                            // B1
+        if (producer) {
+            if (u + 2 < nunits) dma_slab(u + 2);              // into the buffer the compute waves have just left
+            if (a.resid && u + 1 < nunits && (u + 1) % NC == NC - 1) dma_resid((u + 1) / NC);   // staging is free: the previous tile's tail ended before B1
+        }
+        if (u + 1 < nunits) mx96_rebuild_hi6(smem + ((c + 1) & 1) * L1P_SLAB, NPIX, tid, 320);
+        barrier();                                            // B2
+        if (!producer && last_line) {
+            const int p0 = tile_p0(k);
+            int qs[MT];
+            bool valid[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                qs[mt] = p0 + mt * P + wm * 32 + l31;
+                valid[mt] = true;
+            }
+            if (a.resid) {
+                // acc += residual tile through the matrix pipe (conv_dev.h conv_tail_mx: identity A operand); the tiles are resident:
+                // no DMA, no waits.  Fragment f of pixel p: stored slot 2 f + h -> compact slot {0, 1, 2, 3, 4, -, 5, -}
+                bf16x8 iw[4];
+                {
+                    int lo = l31;
+                    asm volatile("" : "+v"(lo));              // opaque: built here for every tile, not kept alive across the tile loop (16 registers)
+                    const int pp = mx_line_pos(lo), f0 = mx6_field_of_pos(pp);
+                    f16x8 k0, k1;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        k0[jj] = (pp == 8 * h + jj) ? (_Float16)1.0f : (_Float16)0.0f;
+                        k1[jj] = (pp == 16 + 8 * h + jj) ? (_Float16)1.0f : (_Float16)0.0f;
+                    }
+                    unsigned q[6];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) {
+                        const int bit = 6 * f0 + 3 - 32 * d;
+                        q[d] = (h == 0 && bit >= 0 && bit < 32) ? (1u << (bit & 31)) : 0u;
+                    }
+                    iw[0] = __builtin_bit_cast(bf16x8, k0);
+                    iw[1] = __builtin_bit_cast(bf16x8, k1);
+                    iw[2] = __builtin_bit_cast(bf16x8, u32x4{q[0], q[1], q[2], q[3]});
+                    iw[3] = __builtin_bit_cast(bf16x8, u32x4{q[4], q[5], 127u, 0u});
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const char* t = stage + (wave * MT + mt) * 3072 + l31 * 96;
+                    bf16x8 x[4];
+                    x[0] = *(const bf16x8*)(t + h * 16);
+                    x[1] = *(const bf16x8*)(t + (2 + h) * 16);
+                    if (h == 0) {
+                        x[2] = *(const bf16x8*)(t + 4 * 16);
+                        x[3] = *(const bf16x8*)(t + 5 * 16);
+                    } else {                                  // (the identity's lo6 half is zero, but a stale scale byte could be NaN)
+                        x[2] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+                        x[3] = x[2];
+                    }
+                    acc[0][mt] = mfma_mx6(acc[0][mt], iw, x);
+                }
+            }
+            conv_epilogue_mx<MT>(a, acc[0], qs, valid, ntile, lane);
+        }
+    }
+    }
+}
+
+static int g_l1p_grid = 0;                               // workgroups of the persistent kernel: one per CU (multiple of 8)
+int g_l1p = 0;                                           // A/B (wsi_conv_set_mode +1048576 ON): the persistent layer-1 kernel (cfg 42) instead of the rows kernel (cfg 40); r05: 45 % slower, off
+static int launch_l1p(const ConvArgs& a, hipStream_t st) {
+    if (a.go.C != 64 || a.gi.C % 32 || a.gi.C < 64 || a.gi.W != 64 || a.gi.H % 4 || a.in2 || a.in_up || !(a.flags & CONV_IN96) ||
+        (a.resid && !(a.flags & CONV_RESID96)))
+        return WSI_EINVAL;
+    if (!g_l1p_grid) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            return WSI_EFAULT;
+        g_l1p_grid = cus / 8 * 8;
+    }
+    const long long mtiles = (long long)a.gi.N * a.gi.H * a.gi.W / 256;
+    int grid = g_l1p_grid;
+    if (mtiles < grid) grid = (int)((mtiles + 7) / 8 * 8);
+    if (a.gi.C != 64) return WSI_EINVAL;                      // (two input lines: the only instantiation)
+    auto k = conv3x3s1_l1p_kernel<2>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, L1P_LDS) != hipSuccess) return WSI_EINVAL;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(320), L1P_LDS, st, a);
+    return hipGetLastError() == hipSuccess ? WSI_OK : WSI_EFAULT;
+}
+
+
+// --------------------------------------------------------------------------------------------
 // "Wide" dense slab kernel (Cout % 128 == 0): every wave owns 64 output channels x 128 pixels (2 x 4 MFMA tiles,
 // 128 accumulator registers), so a pixel-fragment set read from LDS feeds SIX MFMAs instead of three and the
 // operand-load instructions per MFMA drop from 1.67 to 1.0 (the r01 ablations showed the slab3 loop is bound by
@@ -1369,7 +1624,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     ConvArgs a = a_in;
     if (g_xcd_order && cfg >= 20 && cfg < 40 && !CONV_STUDY(a, ~7)) a.flags |= CONV_XCD_ORDER;     // slab3 family only
     if (g_xcd_ranges && !CONV_STUDY(a, ~7) && ((cfg >= 20 && cfg < 42) || cfg == 60 || cfg == 90 || cfg == 91 || (cfg >= 70 && cfg < 90)) && (g_xcd_ranges == 2 || a.go.C == 64)) a.flags |= CONV_XCD_RANGES;
-    if ((a.flags & CONV_IN96) && !((cfg >= 20 && cfg < 42) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // 96-byte input lines: slab3 / row-stacked kernels only
+    if ((a.flags & CONV_IN96) && !((cfg >= 20 && cfg <= 42) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // 96-byte input lines: slab3 / row-stacked kernels only
     if (a.in_up && !((cfg >= 20 && cfg < 40) || cfg == 90 || cfg == 91)) return WSI_EINVAL;   // fused upsample + concat input: slab3 kernels only
     if (cfg < 20) return WSI_EINVAL;                         // (cfg 0-9 were the first slab kernel, removed)
     if (cfg >= 70 && cfg < 90) return wsi_pp_dispatch(a, planes, cfg, st);           // ping-pong kernels (conv_pp.hip)
@@ -1378,6 +1633,7 @@ int wsi_slab_dispatch_cfg(const ConvArgs& a_in, int planes, int cfg, hipStream_t
     // cfg 91: 256 px x 32 couts, the fallback where a 512-pixel tile's slab exceeds the LDS (tiles straddling two images of a wide map)
     if (cfg == 91) return planes == 3 ? launch_slab3<2, 4, 1, 3, 2, true>(a, st) : planes == 2 ? launch_slab3<2, 4, 1, 2, 2, true>(a, st) : WSI_EINVAL;
     // cfg 40 / 41: row-stacked layer-1 kernel (mode 3, 64-wide maps), three / two workgroups per CU
+    if (cfg == 42) return planes == 3 ? launch_l1p(a, st) : WSI_EINVAL;         // r05: persistent, producer-fed form (96-byte lines only)
     if (cfg == 40) return planes == 3 ? launch_rows<3>(a, st) : WSI_EINVAL;
     if (cfg == 41) return planes == 3 ? launch_rows<2>(a, st) : WSI_EINVAL;
     if (cfg == 60) return planes == 3 ? launch_wide<3, 2>(a, st) : planes == 2 ? launch_wide<2, 2>(a, st) : launch_wide<1, 2>(a, st);
@@ -1442,6 +1698,9 @@ static int slab_default_cfg(const ConvArgs& a, int planes, bool fallback) {     
     // against 1.288 / 1.256, profiles/r04_tune_parity.log - so the two parity rules of r02 are gone and the line below decides)
     if (a.go.C % 128 == 0 && a.go.C >= g_wide_min_c && !(planes == 1 && a.gi.W > 33)) return 60;
     if (a.go.C % 128 != 0 && a.gi.W > 128 && !fallback) return 39;       // r02 tune, C = 64 at 256 x 256: 0.94 vs 1.21 ms (cfg 31); at 128 x 128 cfg 31 wins
+    if (a.go.C == 64 && a.gi.C == 64 && planes == 3 && !fallback && g_l1_rows && g_l1p && a.gi.W == 64 && a.gi.H % 4 == 0 && !a.in2 && (a.flags & CONV_IN96) &&
+        (!a.resid || (a.flags & CONV_RESID96)))
+        return 42;                                           // r05 study route (wsi_conv_set_mode +1048576): persistent producer-fed kernel, measured 45 % SLOWER than cfg 40
     if (a.go.C % 128 != 0 && planes == 3 && !fallback && g_l1_rows && a.gi.W == 64 && a.gi.H % 4 == 0 && !a.in2) return 40;   // r04: row-stacked tiles (A/B: wsi_conv_set_mode +1024 off)
     // r04: with the scheduling fences the two-waves-per-SIMD form (cfg 31) beats the fence-less 168-register form (cfg 38) on
     // 16 x 16 maps (cfg4's layer 1, n = 32000: 1.552 vs 1.693 ms); 64-wide maps whose height is no multiple of four keep cfg 38
