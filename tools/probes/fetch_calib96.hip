@@ -58,6 +58,28 @@ __global__ __launch_bounds__(256) void kres(const char* in, long long npix, unsi
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// r05: 96-byte lines are LINE-PLANAR (all pixels' line 0, then line 1): the slab pattern reads contiguous 96-byte pieces of one plane
+__global__ __launch_bounds__(256) void kplanar(const char* in, long long npix, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PIX = 384;
+    const long long p0 = (long long)blockIdx.x * PIX;
+    if (p0 + PIX > npix) return;
+    const int i = wave * 64 + lane, Pl = i >> 3, sl = (i & 7) ^ ((Pl >> 1) & 7);
+    const bool act = sl != 5 && sl != 7;
+    const int voff = Pl * 96 + (sl == 6 ? 5 : sl) * 16;
+    unsigned acc = 0;
+    for (int c = 0; c < 2; ++c) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)c * npix * 96 + p0 * 96), 0, PIX * 96, 0x00020000);
+        for (int i0 = wave * 64, r = 0; i0 < PIX * 8; i0 += 256, ++r)
+            if (act) dma16_buf(rs, smem + (size_t)i0 * 16, voff, r * 32 * 96);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        acc += *(const unsigned*)(smem + tid * 16);
+        __syncthreads();
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 int main(int argc, char** argv) {
     const long long npix = (argc > 1 ? atoll(argv[1]) : 4096) * 4096ll;      // default 16 Mi pixels: 4 GiB / 3 GiB
     char* in; unsigned* sink;
@@ -68,7 +90,9 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k<true>, dim3(grid), dim3(256), 384 * 128, 0, in, npix, sink);
     const int gres = (int)(npix / 256);
     hipLaunchKernelGGL(kres, dim3(gres), dim3(256), 4 * 4096, 0, in, npix, sink);
+    hipLaunchKernelGGL(kplanar, dim3(grid), dim3(256), 384 * 128, 0, in, npix, sink);
     hipDeviceSynchronize();
+    printf("kplanar (96-byte lines, line-planar, slab pattern) needs %lld bytes\n", (long long)grid * 384 * 192);
     printf("needed bytes: k<false> (128-byte lines) %lld, k<true> (96-byte lines) %lld, kres (96-byte lines, residual tile pattern) %lld\n",
            (long long)grid * 384 * 256, (long long)grid * 384 * 192, (long long)gres * 256 * 192);
     return 0;

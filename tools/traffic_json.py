@@ -42,7 +42,9 @@ for which in ('fetch', 'write'):
 # --pmc FETCH_SIZE, profiles/r04_fetch_calib96.txt): the slab pattern is tallied at CAL96_SLAB of its bytes, the tail's residual
 # tile pattern at CAL96_RESID.  Launches alternate without / with a residual, so the per-dispatch counters fall into two
 # clusters: reads(no residual) = A / CAL96_SLAB, reads(residual) = A / CAL96_SLAB + (B - A) / CAL96_RESID.
-CAL96_SLAB = float(os.environ.get('WSI_CAL96_SLAB', '0.945'))
+# r05: 96-byte lines are line-planar - contiguous reads, the guide's x2 rule (factor 0.5) applies to both patterns (kplanar of the probe);
+# r03-r04 (lines interleaved per pixel): slab 0.945, residual 0.5
+CAL96_SLAB = float(os.environ.get('WSI_CAL96_SLAB', '0.5'))
 CAL96_RESID = float(os.environ.get('WSI_CAL96_RESID', '0.5'))
 
 

@@ -13,7 +13,7 @@ int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);
 int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st);
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
 int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
-int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96 = 0);
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96 = 0, long long plane96 = 0);
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
                             float* logits, int planes, hipStream_t st);
 int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
@@ -367,7 +367,7 @@ static int stem_run(const float* in_f32, const uint8_t* slide, long long slide_p
                     int slide_h, int slide_w, const int* tile_xy, const float* lut,
                     const void* stem_wpk, const float* stem_bias, const void* stem_wpk_u8,
                     const float* stem_bias_u8, const float* norm_mean_std, int n, int h, int w,
-                    float* scratch, void* out_pf, int planes, void* stream, int out96) {
+                    float* scratch, void* out_pf, int planes, void* stream, int out96, long long plane96 = 0) {
     if (!stem_wpk || !stem_bias || !scratch || !out_pf || n <= 0 || h % 16 || w % 4) return WSI_EINVAL;
     if (!in_f32 && (!slide || !tile_xy || !lut)) return WSI_EINVAL;
     StemArgs a;
@@ -380,7 +380,7 @@ static int stem_run(const float* in_f32, const uint8_t* slide, long long slide_p
     // for ABI stability and as the caller's statement of which transform those weights carry)
     if (stem_wpk_u8 && stem_bias_u8 && norm_mean_std && !in_f32 && g_stem_u8x) { a.wpk_u8 = stem_wpk_u8; a.bias_u8 = stem_bias_u8; }
     if (out96 && planes != 3) return WSI_EINVAL;
-    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream, out96);
+    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream, out96, plane96);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
     return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
@@ -407,7 +407,8 @@ extern "C" int wsi_study_set_debug(void* dev_buf) { g_study_debug = dev_buf; ret
 static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, const void* wpk, const float* bias, int n,
                        int h_in, int w_in, int cin, int cout, int stride, int ksize, int relu, int planes, void* stream,
                        int cfg = -1, int split_out = 0, long long split_pixels = 0, const void* in2 = nullptr, int in2_c = 0,
-                       const void* wpk2 = nullptr, const float* bias2 = nullptr, int line_flags = 0, const void* in_up = nullptr, int up_c = 0) {
+                       const void* wpk2 = nullptr, const float* bias2 = nullptr, int line_flags = 0, const void* in_up = nullptr, int up_c = 0,
+                       long long plane96 = 0) {
     if ((!in_pf && !(in_up && up_c == cin)) || !out_pf || !wpk || !bias || in_pf == out_pf || in_up == out_pf || n <= 0) return WSI_EINVAL;
     // 96-byte lines (CONV_IN96 / OUT96 / RESID96): mode 3, stride-1 3x3, 64 channels in and out (the slab3 kernel), no phase split
     if (line_flags && (planes != 3 || stride != 1 || ksize != 3 || cin != 64 || cout != 64 || (split_out && (line_flags & CONV_OUT96)) ||
@@ -419,6 +420,7 @@ static int conv_common(const void* in_pf, void* out_pf, const void* resid_pf, co
     a.gi = pf_geom_fd(n, h_in, w_in, cin);
     a.go = pf_geom_fd(n, h_in / stride, w_in / stride, cout);
     a.stride = stride; a.ksize = ksize; a.relu = relu & 1; a.flags = 0;
+    a.plane96 = line_flags ? (plane96 > 0 ? plane96 : (long long)pf_alloc_pixels(n, h_in, w_in) * 96) : 0;   // line-planar 96-byte tensors (common.h)
 #ifdef WSI_STUDY
     // study builds accept the r01 ablation masks of tools/tune_conv.py in `relu` (2 no stores, 64 dispatch only, 128 no main
     // loop, 256 non-temporal, bits 10-13 weight copies, 512 / 16384 XCD orders, 65536 residual read directly)
@@ -917,7 +919,10 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
         if (hipMemsetAsync(ws + p.buf[0][0], 0, nbytes, st) != hipSuccess) return WSI_EFAULT;
     }
     // byte offset of image n0 inside a PF buffer of stage s
-    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * p.sc[s] * (s == 0 && l96 ? 3 : bpc); };
+    // (96-byte lines are line-planar: an image's offset inside every line plane; the planes lie plane96 bytes apart, a distance fixed by
+    //  the plan's capacity, so sub-batches and smaller batches address the same places)
+    auto img_off = [&](int s, int n0) { return (size_t)n0 * (p.sh[s] + 1) * (p.sw[s] + 1) * (s == 0 && l96 ? (size_t)96 : (size_t)p.sc[s] * bpc); };
+    const long long plane96 = l96 ? (long long)pf_alloc_pixels(cap, p.sh[0], p.sw[0]) * 96 : 0;
     // ... and inside one phase image of stage 0's phase-split output (a PF tensor of stage 1's map size, 64 channels)
     auto split_off = [&](int n0) { return (size_t)n0 * (p.sh[1] + 1) * (p.sw[1] + 1) * p.sc[0] * bpc; };
 
@@ -931,7 +936,7 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                           slide_w, tile_xy ? tile_xy + 2 * n0 : nullptr, lut, wt->stem_w, wt->stem_b,
                           wt->stem_w_u8, wt->stem_b_u8, wt->norm,
                           nn, h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0] + img_off(0, n0),
-                          planes, st, l96 ? 1 : 0);
+                          planes, st, l96 ? 1 : 0, plane96);
             prof_close(st, pi_);
             if (rc) return rc;
         }
@@ -944,15 +949,15 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
             const int f_in = l96 ? CONV_IN96 : 0, f_res = l96 ? CONV_RESID96 : 0;
             PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(x, mid, nullptr, wt->conv_w[2 * b], wt->conv_b[2 * b], nn1,
                                                               H1, W1, 64, 64, 1, 3, 1, planes, st, -1, 0, 0, nullptr, 0, nullptr, nullptr,
-                                                              f_in | (l96 ? CONV_OUT96 : 0)));
+                                                              f_in | (l96 ? CONV_OUT96 : 0), nullptr, 0, plane96));
             if (b == 1 && split0) {                    // layer1's output feeds only the stride-2 entry of layer2
                 PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, ws + p.buf[0][3] + split_off(n1), x, wt->conv_w[3], wt->conv_b[3], nn1, H1, W1, 64,
                                                                   64, 1, 3, 1, planes, st, -1, 1, pf_alloc_pixels(cap, H1 / 2, W1 / 2), nullptr, 0, nullptr,
-                                                                  nullptr, f_in | f_res));
+                                                                  nullptr, f_in | f_res, nullptr, 0, plane96));
             } else {                                   // (the stage's last conv writes 128-byte lines: layer 2, taps and skips read those)
                 PROF_CONV(5, nn1, H1, W1, 64, 64, 9, conv_common(mid, out, x, wt->conv_w[2 * b + 1], wt->conv_b[2 * b + 1],
                                                                   nn1, H1, W1, 64, 64, 1, 3, 1, planes, st, -1, 0, 0, nullptr, 0, nullptr, nullptr,
-                                                                  f_in | f_res | (l96 && b == 0 ? CONV_OUT96 : 0)));
+                                                                  f_in | f_res | (l96 && b == 0 ? CONV_OUT96 : 0), nullptr, 0, plane96));
             }
             cur = o;
         }

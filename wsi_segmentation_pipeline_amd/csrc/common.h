@@ -145,6 +145,11 @@ struct ConvArgs {
     const void* in_up = nullptr;
     int up_c = 0;
     PFGeom gup = {};
+    // 96-byte-line tensors (CONV_IN96 / OUT96 / RESID96) are LINE-PLANAR since r05: all pixels' line 0 (96 bytes each, pixel stride 96),
+    // then all pixels' line 1, ... - plane96 = bytes from one 32-channel line plane to the next (in, out and resid of a layer-1 conv share
+    // one geometry and one plan).  r03-r04 interleaved the lines per pixel (96 of every 192 bytes per slab load); tools/probes/slab_pattern
+    // measured that pattern at 3.8 TB/s against 7.1-7.3 TB/s for contiguous 96-byte lines (profiles/r05_slab_pattern_probe.txt).
+    long long plane96 = 0;
 };
 
 // ConvArgs.flags.  Product flags first; the CONV_ABL_* / study ones only act in builds with -DWSI_STUDY (bottleneck
@@ -156,7 +161,7 @@ enum : int {
     // 96-byte activation lines (mode 3; the trunk's 64-channel layer 1, which is HBM-bound): the line in memory is
     // [fp16 plane 64 B][lo6 dwords 0-3][lo6 dwords 4-5, scale_lo, scale_hi] - the hi6 plane, which is the fp6 image of the fp16
     // plane, is not stored; a consumer rebuilds it in LDS after its slab has landed (conv_dev.h mx96_rebuild_hi6), where lines
-    // keep their 128-byte pitch.  Pixel stride 3 bytes per channel.
+    // keep their 128-byte pitch.  The tensor is line-planar (ConvArgs.plane96): pixel stride 96 bytes inside a line plane.
     CONV_IN96 = 16, CONV_OUT96 = 32, CONV_RESID96 = 64,
     CONV_ABL_NO_STORE = 1 << 8, CONV_ABL_DISPATCH_ONLY = 1 << 9, CONV_ABL_NO_MAINLOOP = 1 << 10, CONV_NONTEMPORAL = 1 << 11,
     CONV_WCOPIES_SHIFT = 16,   // bits 16-19: back-to-back copies of the packed weights minus one

@@ -162,10 +162,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
     const int P = a.gi.P;
     const int ntile = nb * WN + wn;
     const int NC = CONV_STUDY(a, CONV_ABL_NO_MAINLOOP) ? 0 : a.gi.C / PFmt<PLANES>::CPL;  // study builds: epilogue only
-    const bool in96 = PLANES == 3 && (a.flags & CONV_IN96);   // 96-byte input lines (common.h): 3 bytes per channel in memory, 128-byte lines in LDS
+    const bool in96 = PLANES == 3 && (a.flags & CONV_IN96);   // 96-byte input lines (common.h): line-planar in memory, 128-byte lines in LDS
     const int ncup = a.in_up ? a.up_c / PFmt<PLANES>::CPL : 0;    // leading lines that come from the half-size tensor (U-Net decoder)
-    const size_t in_pixstride = (size_t)(a.gi.C - (a.in_up ? a.up_c : 0)) * (in96 ? 3 : PFmt<PLANES>::BPC);
-    const int in_line = in96 ? 96 : 128;
+    const size_t in_pixstride = in96 ? (size_t)96 : (size_t)(a.gi.C - (a.in_up ? a.up_c : 0)) * PFmt<PLANES>::BPC;
+    const int in_line = in96 ? 0 : 128;                       // (96-byte lines: the line's plane is part of the resource base)
     int xoff[MT], qs[MT];                                     // slab-local pixel / PF position of each tile row
     bool valid[MT];
     int slab0, npieces;
@@ -270,8 +270,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void conv3x3s1_slab3_kernel(Conv
                 dma16_buf(urs, smem + (size_t)i0 * 16, src * up_pixstride + usl * 16, c * 128);
             }
         } else {
+            const __amdgpu_buffer_rsrc_t xr = in96 ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (size_t)c * (size_t)a.plane96 + slab_byte0), 0,
+                                                                                        (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000)
+                                                   : xrs;
             for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-                if (xact) dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, (c - ncup) * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
+                if (xact) dma16_buf(xr, smem + (size_t)i0 * 16, xvoff, (c - ncup) * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -437,8 +440,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
     const int ntile = nb * WN + wn;
     const int NC = NCT ? NCT : a.gi.C / 32;
     constexpr bool in96 = IN96;
-    const size_t in_pixstride = (size_t)a.gi.C * (in96 ? 3 : 4);
-    const int in_line = in96 ? 96 : 128;
+    const size_t in_pixstride = in96 ? (size_t)96 : (size_t)a.gi.C * 4;     // 96-byte lines are line-planar (ConvArgs.plane96)
+    const int in_line = in96 ? 0 : 128;                       // (96-byte lines: the line's plane is part of the resource base)
     // tile = four whole rows of one image (the launcher checks W == 64, H % 4 == 0)
     const int p0 = pf_pos_of_index(a.gi, mtile * BM);         // first pixel of the tile's first row
     const int slab0 = p0 - P - 1;
@@ -484,8 +487,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3s1_rows_kernel(ConvArgs a) {
     for (int c = 0; c < (NCT ? NCT : NC); ++c) {
         WSTAMP(st_a = __builtin_readcyclecounter();)
         if (c) __syncthreads();
-        for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
-            if (xact) dma16_buf(xrs, smem + (size_t)i0 * 16, xvoff, c * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
+        {
+            const __amdgpu_buffer_rsrc_t xr = in96 ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (size_t)c * (size_t)a.plane96 + slab_byte0), 0,
+                                                                                        (int)min(in_bytes - slab_byte0, (size_t)0x7fffffff), 0x00020000)
+                                                   : xrs;
+            for (int i0 = wave * 64, r = 0; i0 < npieces; i0 += NTHREADS, ++r)
+                if (xact) dma16_buf(xr, smem + (size_t)i0 * 16, xvoff, c * in_line + r * (NTHREADS / 8) * (int)in_pixstride);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         WSTAMP(if (c) st_line += __builtin_readcyclecounter() - st_a; else st_pro = __builtin_readcyclecounter() - st_a; st_a = __builtin_readcyclecounter();)
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(320, 1) void conv3x3s1_l1p_kernel(ConvArgs a) {
     const int wm = (wave >> 1) & 1, wn = wave & 1;            // compute waves: column half of the 64-wide map, channel tile
     const int l31 = lane & 31, h = lane >> 5;
     constexpr int NC = NCT;                                   // input lines (the line loop is unrolled: accumulators live inside one tile iteration)
-    const int in_pixstride = a.gi.C * 3;                      // 96-byte lines
+    const int in_pixstride = 96;                              // 96-byte lines, line-planar (ConvArgs.plane96)
     // this workgroup's tiles: XCD x (= id & 7) owns a contiguous range of tiles, its workgroups take them round-robin, so the tiles in
     // flight on one XCD are neighbours (they share halo rows in that XCD's L2)
     const int mtiles = (a.gi.N * a.gi.H * a.gi.W) >> 8;
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(320, 1) void conv3x3s1_l1p_kernel(ConvArgs a) {
         sact[par] = mx96_stored(sl);
     }
     // residual tile: 192 pieces (32 pixels x 6 stored slots, 96-byte pitch in the staging area) in three instructions
-    const int r_pixstride = a.go.C * 3;
+    const int r_pixstride = 96;
     int rv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -646,27 +654,28 @@ __global__ __launch_bounds__(320, 1) void conv3x3s1_l1p_kernel(ConvArgs a) {
         const int k = u / NC, c = u - k * NC;
         const size_t byte0 = (size_t)(tile_p0(k) - P - 1) * in_pixstride;
         const size_t in_bytes = (size_t)pf_alloc_pixels(a.gi.N, a.gi.H, a.gi.W) * in_pixstride;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + byte0), 0,
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (size_t)c * (size_t)a.plane96 + byte0), 0,
                                                                              (int)min(in_bytes - byte0, (size_t)0x7fffffff), 0x00020000);
         const unsigned dst = lds_addr_of(smem + (u & 1) * L1P_SLAB);
         for (int r = 0; r < (NPIX * 8 + 63) / 64; ++r) {
             const bool on = sact[r & 1] && (r * 64 + lane) < NPIX * 8;
-            if (on) dma16_buf_asm(rs, dst + r * 1024, sv[r & 1], c * 96 + r * 8 * in_pixstride);
+            if (on) dma16_buf_asm(rs, dst + r * 1024, sv[r & 1], r * 8 * in_pixstride);
         }
     };
     auto dma_resid = [&](int k) {                             // the sixteen residual tiles of tile k -> staging area
         const int p0 = tile_p0(k);
         const size_t byte0 = (size_t)p0 * r_pixstride;
         const size_t r_bytes = (size_t)pf_alloc_pixels(a.go.N, a.go.H, a.go.W) * r_pixstride;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.resid + byte0), 0,
-                                                                             (int)min(r_bytes - byte0, (size_t)0x7fffffff), 0x00020000);
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < 4; ++w) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.resid + (size_t)(w & 1) * (size_t)a.plane96 + byte0), 0,
+                                                                                 (int)min(r_bytes - byte0, (size_t)0x7fffffff), 0x00020000);   // line wn's plane
             for (int mt = 0; mt < MT; ++mt) {
-                const int soff = (mt * P + (w >> 1) * 32) * r_pixstride + (w & 1) * 96;      // tile (wave w, row mt): pixels p0 + mt P + 32 wm + 0..31, line wn
+                const int soff = (mt * P + (w >> 1) * 32) * r_pixstride;                     // tile (wave w, row mt): pixels p0 + mt P + 32 wm + 0..31
                 const unsigned dst = lds_addr_of(stage + (w * MT + mt) * 3072);
 #pragma unroll
                 for (int k3 = 0; k3 < 3; ++k3) dma16_buf_asm(rs, dst + k3 * 1024, rv[k3], soff);
             }
+        }
     };
     auto barrier = [&]() {                                    // raw barrier: LDS traffic of this wave is complete, nothing else is drained
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -276,12 +276,12 @@ template <int MT, int MTN = MT>
 static __device__ __forceinline__ void conv_epilogue_mx(const ConvArgs& a, f32x16 (&acc)[MT], const int (&qs)[MT],
                                                         const bool (&valid)[MT], int ntile, int lane, int mt0 = 0) {
     const int h = lane >> 5;
-    const bool o96 = a.flags & CONV_OUT96;                                            // 96-byte lines (ordinary PF only, never phase-split)
-    const size_t pixstride = (size_t)a.go.C * (o96 ? 3 : 4);
+    const bool o96 = a.flags & CONV_OUT96;                                            // 96-byte lines (ordinary PF only, never phase-split): line-planar
+    const size_t pixstride = o96 ? (size_t)96 : (size_t)a.go.C * 4;
     const float lo_clamp = a.relu ? 0.f : -65504.f;
 #pragma unroll
     for (int mt = mt0; mt < mt0 + MTN; ++mt) {
-        const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (size_t)ntile * (o96 ? 96 : 128);
+        const size_t loff = (size_t)(valid[mt] ? qs[mt] : a.go.G) * pixstride + (o96 ? (size_t)ntile * (size_t)a.plane96 : (size_t)ntile * 128);
         f32x16 v = acc[mt];
         f32x16 hi, lo;
         f16x8 hv[2];
@@ -342,8 +342,8 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
         return;
     }
     const int h = lane >> 5, l31 = lane & 31;
-    const bool r96 = a.flags & CONV_RESID96;                    // the residual tensor has 96-byte lines
-    const int pixstride = a.go.C * (r96 ? 3 : 4);
+    const bool r96 = a.flags & CONV_RESID96;                    // the residual tensor has 96-byte lines (line-planar: ConvArgs.plane96)
+    const int pixstride = r96 ? 96 : a.go.C * 4;
     // the residual from the slab's first pixel on (slab0 = the workgroup's first input pixel = a pixel of the residual too)
     const size_t rbase = (size_t)slab0 * pixstride, rbytes = (size_t)pf_alloc_pixels(a.go.N, a.go.H, a.go.W) * pixstride;
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.resid + rbase), 0,
@@ -372,7 +372,11 @@ static __device__ __forceinline__ void conv_tail_mx(const ConvArgs& a, f32x16 (&
         const int nt = k / MT, mt = k % MT;
         int qr = qs[mt] - slab0;                                // (rows past the end repeat the tile's last pixel: a real one)
         asm volatile("" : "+v"(qr));                            // opaque: offsets are rebuilt per batch, not kept alive across the encodes
-        if (r96) resid_tile_dma_buf96(rrs, qr, pixstride, (ntile0 + nt) * 96, lane, scratch + (k % NBUF) * 4096);
+        if (r96) {                                              // the channel tile's own line plane (a plane can exceed the 2 GB a resource spans)
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)a.resid + (size_t)(ntile0 + nt) * (size_t)a.plane96 + rbase), 0, (int)min(rbytes - rbase, (size_t)0x7fffffff), 0x00020000);
+            resid_tile_dma_buf96(prs, qr, pixstride, 0, lane, scratch + (k % NBUF) * 4096);
+        }
         else resid_tile_dma_buf(rrs, qr, pixstride, (ntile0 + nt) * 128, lane, scratch + (k % NBUF) * 4096);
     };
     const int xb = l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);

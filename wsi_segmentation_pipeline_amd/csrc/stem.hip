@@ -247,7 +247,8 @@ struct StemPoolArgs {
     StemArgs s;              // s.out unused
     void* out_pf;            // PF (H/4, W/4, 64)
     int rows_per_seg;        // pooled rows per workgroup
-    int out96;               // OUT == 3: 96-byte output lines (common.h CONV_OUT96)
+    int out96;               // OUT == 3: 96-byte output lines (common.h CONV_OUT96), line-planar:
+    long long plane96;       // bytes from the 32-channel line plane of wave 0's channels to wave 1's (ConvArgs.plane96)
 };
 
 constexpr int SP_COLS = 70;                  // input columns per strip (2*31 + 8: the widest lane's 16-byte read)
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
     const float col_ub = col_ok ? (OUT == 3 ? 65504.f : 3.4028234e38f) : 0.f;
     const int lc = (even || l31 < 31) ? l31 : 30;                       // odd layout: lane 31 is idle, keep its reads inside the row
     const bool o96 = OUT == 3 && A.out96;
-    const size_t pixstride = (size_t)64 * (o96 ? 3 : PFmt<OUT>::BPC);
+    const size_t pixstride = o96 ? (size_t)96 : (size_t)64 * PFmt<OUT>::BPC;
     PFGeom go = pf_geom(a.N, Hp, Wp, 64);
 
     // every wave of the workgroup makes the same number of trips (one barrier each); strips with fewer rows idle at the end
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 swap32_halves(lo, hi);
                 const u32x6 q = mx6_pack32(lo, hi, sb ? mx_scale_value(sb) : 1.f);
                 if (store) {                                                        // line order: common.h mx_line_pos / mx6_field_of_pos
-                    char* ol = o + wave * (o96 ? 96 : 128);
+                    char* ol = o + (o96 ? (size_t)wave * (size_t)A.plane96 : (size_t)wave * 128);
                     *(f16x8*)(ol + 32 * h) = hv[0];
                     *(f16x8*)(ol + 32 * h + 16) = hv[1];
                     if (!o96) {
@@ -610,10 +611,11 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
 }
 
 int g_stem_shared_weights = 1;                        // A/B: wsi_stem_set_mode(fused = 3) selects the one-strip form (weights in registers)
-int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96) {
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96, long long plane96) {
     if (a.H % 4 || a.W % 4 || a.N <= 0 || planes < 1 || planes > 3 || rows_per_seg <= 0) return WSI_EINVAL;
     StemPoolArgs A;
-    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg; A.out96 = out96;
+    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg; A.out96 = out96; A.plane96 = plane96;
+    if (out96 && plane96 <= 0) return WSI_EINVAL;
     const int Hp = a.H / 4, Wp = a.W / 4;
     const long long grid = (long long)a.N * (Wp <= 16 ? 1 : (Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);   // strips, see kernel
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
