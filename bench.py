@@ -383,7 +383,7 @@ def run_rank(args):
             # tools/traffic_json.py), WRITE_SIZE exact
             nl = sum(v['launches'] for v in l1_sel)
             traffic_l1 = round(sum(v['hbm_bytes_per_launch_calibrated96'] * v['launches'] for v in l1_sel) / nl * sc)
-        roofline_l1 = {'kernel': 'conv3x3s1_rows_kernel (r04; 4 launches per batch: the 64-channel layer 1 on 64-wide maps)', 'bound': 'hbm',
+        roofline_l1 = {'kernel': 'conv3x3s1_rows_kernel (4 launches per batch: the 64-channel layer 1 on 64-wide maps; line-planar 96-byte lines since r05)', 'bound': 'hbm',
                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                        'traffic': traffic_l1,
                        'algorithmic_bytes_per_launch': round(alg), 'line_bytes': 96 if lines96 else 128,
@@ -393,8 +393,8 @@ def run_rank(args):
             roofline_l1['traffic_parts'] = {
                 'write_bytes_per_launch': round(sum(v['write_bytes_per_launch'] * v['launches'] for v in l1_sel) / nl * sc),
                 'fetch_size_raw_bytes_per_launch': round(sum(v['read_bytes_per_launch'] * v['launches'] for v in l1_sel) / nl * sc / 2),
-                'note': ('FETCH_SIZE of 96-byte-line reads is calibrated per pattern (tools/traffic_json.py): slab reads are tallied at x0.972 of '
-                         'their bytes, the residual tile reads at x0.5') if traffic_l1 else
+                'note': ('96-byte lines are line-planar since r05: contiguous reads, FETCH_SIZE follows the x2 rule for the slab and the residual-tile '
+                         'pattern alike (tools/probes/fetch_calib96 kplanar: x0.500, profiles/r05_fetch_calib96.txt; r03-r04, lines interleaved per pixel: x0.945 / x0.5)') if traffic_l1 else
                         'FETCH_SIZE uncalibrated for 96-byte-line reads (x1.03 .. x2): no total; algorithmic reads are 59 % of the algorithmic bytes'}
 
     # stem (tile read + transform + conv7x7 + BN + ReLU + maxpool, one launch per batch): HBM-side roofline.  Algorithmic bytes per tile =

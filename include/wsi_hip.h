@@ -10,12 +10,18 @@
  *   - every device function takes a hipStream_t (passed as void*), enqueues asynchronously and
  *     returns 0 or a negative errno (-22 EINVAL bad shape/argument, -14 EFAULT launch failure);
  *     nothing throws, nothing allocates: workspaces are caller-owned
- *   - planes = 2 ("parity"): bf16x2 split operands, three MFMA passes.  Max |logit - reference| on the five reference-generated
- *                  margin families (tests/golden/margin_*.npz, tests/test_gpu_margin.py): 4.0e-4; 3e-5 on the default fixtures
+ *   - planes = 2 ("parity"): fp16 hi + fp16 lo operand pair (r05; r01-r04: a bf16 pair), three MFMA passes, fp32 accumulate: 22
+ *                  significand bits per operand where both halves are normal fp16 numbers, 2^-25 absolute where lo is subnormal;
+ *                  packed weights carry one power-of-two scale per output channel (largest |weight| of a channel in [2^13, 2^14)), so
+ *                  weights of any magnitude fit.  Max |logit - reference| on the five reference-generated margin families
+ *                  (tests/golden/margin_*.npz, tests/test_gpu_margin.py): 2.0e-5 (bf16 pair: 4.0e-4); 5e-6 on the bench tiles; dense
+ *                  per-pixel U-Net logits at |logit| 16: 1.2e-4 (bf16 pair: 1.01e-3, over the 1e-3 contract).  Activations are
+ *                  clamped to the fp16 range (+-65504) when a conv writes them, as in mode 3.
  *     planes = 3 ("mx", the default): fp16 main pass + MX-fp6 (e2m3) block-scaled cross terms, one E8M0 scale per 32 channels
- *                  and plane: three MFMA instructions per step instead of six.  6.3e-4 on the same five families (|logit| up
- *                  to 16), 1e-4 on the default fixtures: inside the 1e-3 contract everywhere it was measured.  (r01-r02
- *                  shipped fp4 cross terms in the same line: 1.9e-3 on two of the families - outside the contract.)
+ *                  and plane: three MFMA instructions per step instead of six.  4.6e-4 on the same five families (|logit| up
+ *                  to 16), 1e-4 on the default fixtures: inside the 1e-3 contract everywhere it was measured (profiles/r05_margin_families.json);
+ *                  2.2e-3 on the dense per-pixel path: NOT a contract mode there.  (r01-r02 shipped fp4 cross terms in the same line:
+ *                  1.9e-3 on two of the families.)
  *     planes = 1 ("speed"): single-pass bf16, logit error ~2e-2: roofline studies only, never a
  *                  contract mode
  *   - "PF" = padded-flat activation layout, see wsi_pf_* below and DESIGN.md
@@ -29,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WSI_HIP_ABI_VERSION 4
+#define WSI_HIP_ABI_VERSION 5            /* r05: planes 2 = fp16 pair, its packed conv weights end in cout inverse channel scales */
 int wsi_hip_abi_version(void);
 
 /* ---- padded-flat layout helpers (host) -------------------------------------------------------
@@ -44,7 +50,8 @@ long long wsi_pf_pixel_index(int n, int y, int x, int h, int w);
  * emits them in per-lane MFMA operand order.  bn_* may be NULL (no BN: scale 1, bias 0).
  *   conv: w OIHW fp32 [cout][cin][k][k], k in {1,3}, cout % 32 == 0, cin a whole number of 128-byte lines (cin % 64 == 0 for
  *         planes 1, cin % 32 == 0 for planes 2 / 3; 32-channel tensors are served by the stride-1 3x3 convolution only)
- *         wpk_out: wsi_prepack_conv_bytes() bytes; bias_out: cout floats
+ *         wpk_out: wsi_prepack_conv_bytes() bytes (planes 2: the fragment blocks, then cout floats = the inverse of the power-of-two
+ *         scale each output channel's weights were multiplied by; the kernels apply it before the bias); bias_out: cout floats
  *   stem: w [64][3][7][7] (resnets_shift.py:122)  */
 size_t wsi_prepack_conv_bytes(int cout, int cin, int k, int planes);
 int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bias, const float* bn_mean,
@@ -129,7 +136,9 @@ int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* 
  * per workgroup on the layer-3 / layer-4 entries (mode 3; bit-identical), +1024 the 64-channel layer 1 on the r03 slab3 kernel instead of
  * the row-stacked kernel (mode 3, 64-wide maps; results equal to a few ulps of the fp32 sums: another summation order), +65536 the
  * U-Net decoder blocks write the upsampled + concatenated tensor before their first conv instead of reading both sources in it
- * (bit-identical).  Process-wide. */
+ * (bit-identical), +131072 the wide stride-1 kernel keeps the 9-pixel slab pitch on 8 x 8 maps (r05 default: 8-pixel slab rows, no LDS
+ * bank conflicts; bit-identical), +1048576 the 64-channel layer 1 on the persistent producer-fed kernel (r05 study route: bit-identical,
+ * measured 30-45 % slower than the row-stacked kernel).  Process-wide. */
 int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */

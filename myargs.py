@@ -27,7 +27,7 @@ _FLAGS = [
     ('epsilon', 1e-8, float),
 ]
 
-parser = argparse.ArgumentParser()
+parser = argparse.ArgumentParser(allow_abbrev=False)     # (a host program's own --mode must not be read as an abbreviation of --model_name)
 for _name, _default, _type in _FLAGS:
     parser.add_argument('--' + _name, default=_default, type=_type)
 

@@ -135,7 +135,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 4                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
+ABI_VERSION = 5                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
 
 
 def load():
