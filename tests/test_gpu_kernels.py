@@ -66,6 +66,29 @@ def _conv_case(dev, n, cin, cout, h, w, stride, ksize, resid, relu, planes, seed
     return _rel_err(got, ref)
 
 
+def test_parity_weight_scales_cover_any_magnitude(dev):
+    """Mode 2 (fp16 pair, r05): wsi_prepack_conv multiplies every output channel's folded weights by a power of two that puts the
+    channel's largest magnitude into [2^13, 2^14) and the epilogue divides the accumulators by it - so channels whose weights sit deep in
+    fp16's subnormals (6e-5 x N(0, 1): without the scale their lo parts would all be subnormal, ~1e-3 relative) or far above 1 (gains 1e-3 ...
+    1e3 across the channels of one conv; activations of ordinary size) keep the pair's precision, and an all-zero channel stays zero."""
+    from wsi_segmentation_pipeline_amd import engine as E
+    g = torch.Generator().manual_seed(17)
+    n, cin, cout, h, w = 2, 64, 64, 16, 16
+    x = torch.randn(n, cin, h, w, generator=g).abs_()
+    gain = torch.logspace(3, -3, cout).view(-1, 1, 1, 1)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5 * gain
+    wt[5] = 0
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    wpk, bias = E.prepack_conv(wt, None, 2, dev)
+    out = E.pf_unpack(E.conv_bn_act(E.pf_pack(x.to(dev), 2), n, h, w, cin, cout, wpk, bias, 1, 3, None, False, 2), n, cout, h, w, 2).cpu().double()
+    scale = ref.abs().amax((0, 2, 3)).clamp_min(1e-300)                    # per output channel: each has its own magnitude
+    rel = ((out - ref).abs().amax((0, 2, 3)) / scale)
+    rel[5] = out[:, 5].abs().max()                                         # the zero channel: exactly zero
+    print('per-channel rel err: max %.2e (channel %d)' % (float(rel.max()), int(rel.argmax())))
+    assert float(rel.max()) <= 2e-5                                        # (outputs above 65504 would be clamped: none here)
+    assert float(ref.abs().max()) < 65504
+
+
 CONV_S1 = [  # n, cin, cout, h, w
     (3, 64, 64, 16, 16), (2, 64, 64, 64, 64), (5, 128, 128, 8, 8), (2, 128, 128, 32, 32),
     (3, 256, 256, 4, 4), (2, 256, 256, 16, 16), (7, 512, 512, 2, 2), (3, 512, 512, 8, 8), (1, 64, 128, 8, 8),

@@ -258,7 +258,7 @@ class TrunkEngine:
 
     def _auto_cap(self, h, w):
         """Default images per trunk call: the tuned batch scaled by patch area, limited so that the workspaces of all stream slots
-        stay inside 40 % of the memory that is free now (plus what this engine already holds)."""
+        stay inside 60 % of the memory that is free now (plus what this engine already holds)."""
         want = max(1, int(self.TUNED_BATCH_256 * 65536 // max(h * w, 1)))
         per = self.lib.wsi_trunk_workspace_bytes(64, h, w, self.planes) / 64.0
         if per <= 0:
@@ -269,7 +269,7 @@ class TrunkEngine:
             return want
         held = sum(int(ws.numel()) for ws, _ in self._ws.values())
         slots = max(1, len(self._streams))
-        return max(1, min(want, int(0.4 * (free + held) / (slots * per))))
+        return max(1, min(want, int(0.6 * (free + held) / (slots * per))))
 
     def _batched(self, n, run, h=256, w=256):
         """Split n images into max_batch chunks; with several chunks, alternate them over the side streams."""
