@@ -66,6 +66,18 @@ def _device_of(model):
     return p.device
 
 
+def _to_host(*tensors):
+    """Device tensors -> NumPy arrays: asynchronous copies into pinned host buffers, ONE synchronisation for all of them."""
+    outs = []
+    for t in tensors:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=t.is_cuda)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    if any(t.is_cuda for t in tensors):
+        torch.cuda.current_stream().synchronize()
+    return tuple(h.numpy() for h in outs)
+
+
 def _save_png(arr, path):
     from PIL import Image
     Image.fromarray(arr).save(path)
@@ -92,7 +104,8 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
             ref_level = min(2, len(scan.level_dimensions) - 1)
             map_hw = scan.level_dimensions[ref_level][::-1]
             m = scan.level_downsamples[args.scan_level] / scan.level_downsamples[ref_level]
-            mask = torch.from_numpy(np.ascontiguousarray(entry['mask'])).to(dev) if entry.get('mask') is not None else None
+            # (pinned staging + asynchronous copy: a pageable-memory copy would block the host until everything enqueued so far has run)
+            mask = S._upload(entry['mask'], torch.as_tensor(entry['mask']).dtype, dev) if entry.get('mask') is not None else None
             if mode == 'cls' and isinstance(model, SlideClassifierModel):
                 # fused fast path: the stem kernel reads the HBM-resident slide directly
                 level = scan.device_level(args.scan_level, dev)
@@ -155,8 +168,8 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
             if r.get('exponent_span') is not None:             # the float64 stitch is exact (order- and rank-independent) inside this
                 over = (-(-ds.params.ph // ds.params.sh) + 1) * (-(-ds.params.pw // ds.params.sw) + 1)      # bound; outside it the map
                 stitch_exact = E.stitch_is_exact(r['exponent_span'], over)                                   # is right to float64 rounding only
-            heat = r['heatmap'].cpu().numpy()
-            results[key] = {'heatmap': heat, 'classes': r['classes'].cpu().numpy(), 'logits': r['logits'],
+            heat, classes_np = _to_host(r['heatmap'], r['classes'])          # both u8 maps in one round trip through pinned memory
+            results[key] = {'heatmap': heat, 'classes': classes_np, 'logits': r['logits'],
                             'precision': r.get('precision'),          # precision='auto': the mode this slide ran in, and why
                             'stitch_exact': stitch_exact}
             if save and rank == 0:
