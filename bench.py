@@ -518,7 +518,22 @@ def run_rank(args):
         import utils.eval as UE
         from models.models import Classifier
         from PIL import Image
-        eng.release_workspaces()
+        # the bare engine under the SAME conditions as the API calls below - one slide per call, a host synchronisation after each, this
+        # late in the run (clocks settle lower than in the timed region, and back-to-back steps of the timed region overlap at their ends)
+        ts_ref = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            ts_ref.append(time.perf_counter() - r0)
+        t_ref = float(np.median(ts_ref[1:]))
+        # The API's own engines plan their own 2 x 51 GB beside the timed region's: releasing those first and re-allocating costs the API
+        # engine 3 % (218.6 against 212.3 ms for the same 24 648 tiles; a first allocation in a fresh process: 207.6 - where its workspaces
+        # land in HBM matters, profiles/r05_api_breakdown.txt), so they are only released when the memory is needed
+        if torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev) < 130e9:
+            eng.release_workspaces()
+            torch.cuda.empty_cache()
         net = resnets_shift.resnet18(False)                  # precision='auto' is the constructor default
         net.load_state_dict(sd, strict=False)                # (the seeded checkpoint has no bag-head keys: fc / fc1 / fc2 stay as initialised, unused here)
         head = Classifier(512, 4)
@@ -544,13 +559,39 @@ def run_rank(args):
             res = UE.predict_tumorbed(model, dsw, 0, mode='cls', save=False)['bench.svs']      # warm-up (plans the workspaces)
             torch.cuda.synchronize()
             ts, ts_png = [], []
+            marks = []
+            if os.environ.get('WSI_API_MARKS') == '1':             # diagnosis: synchronised stopwatch inside the call (tools/api_breakdown.py)
+                orig_infer = S.infer_slide_cls
+
+                def mark(name):
+                    torch.cuda.synchronize()
+                    marks.append((name, time.perf_counter()))
+
+                def timed_infer(e_, *a_, **k_):
+                    mark('enter infer')
+                    mxf, parf = e_._mx.forward_tiles, e_._par.forward_tiles
+                    e_._mx.forward_tiles = lambda *x, **y: (mxf(*x, **y), mark('mx done'))[0]
+                    e_._par.forward_tiles = lambda *x, **y: (parf(*x, **y), mark('parity sample done'))[0]
+                    try:
+                        r_ = orig_infer(e_, *a_, **k_)
+                    finally:
+                        e_._mx.forward_tiles, e_._par.forward_tiles = mxf, parf
+                    mark('leave infer')
+                    return r_
+                UE.S.infer_slide_cls = timed_infer
             for rep in range(3):
                 dsw = make_dataset()
                 torch.cuda.synchronize()
                 a0 = time.perf_counter()
+                marks[:] = [('start', a0)]
                 res = UE.predict_tumorbed(model, dsw, 0, mode='cls', save=False)['bench.svs']
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - a0)
+                if len(marks) > 1:
+                    marks.append(('end', time.perf_counter()))
+                    print('api rep %d: ' % rep + ' | '.join('%s +%.2f' % (marks[i][0], (marks[i][1] - marks[i - 1][1]) * 1e3) for i in range(1, len(marks))), file=sys.stderr)
+            if os.environ.get('WSI_API_MARKS') == '1':
+                UE.S.infer_slide_cls = orig_infer
             dsw = make_dataset()
             a0 = time.perf_counter()
             UE.predict_tumorbed(model, dsw, 0, mode='cls')                                       # save=True: + heat-map and overlay PNGs, as the reference writes them
@@ -564,6 +605,10 @@ def run_rank(args):
         same = bool(np.array_equal(res['heatmap'], out['heatmap'].cpu().numpy())) if res['precision'] and res['precision'].get('mode') == args.mode else None
         api = {'value': round(n_api / t_api, 1), 'unit': unit, 'ms_per_slide': round(t_api * 1e3, 3), 'tiles': n_api,
                'vs_headline': round(n_api / t_api / value, 4),
+               'bare_engine_one_slide_per_call': {'value': round(n_api / t_ref, 1), 'ms_per_slide': round(t_ref * 1e3, 3),
+                                                  'note': 'slide.infer_slide_cls on the hand-built engine of the timed region, one call + one synchronisation per slide, '
+                                                          'measured right before the API calls (median of 3 after one warm-up)'},
+               'vs_bare_engine_one_slide_per_call': round(t_ref / t_api, 4),
                'call': "utils.eval.predict_tumorbed(SlideClassifierModel(resnets_shift.resnet18(), models.models.Classifier(512, 4)), utils.dataset.Dataset_wsis(...), ep, mode='cls', save=False)",
                'precision': res['precision'], 'engine_defaults': {'batches_in_flight': max(1, len(getattr(inner, '_streams', []))),
                                                                   'batch_cap': inner._auto_cap(TILE, TILE) if hasattr(inner, '_auto_cap') else None},

@@ -521,6 +521,48 @@ def test_auto_precision_is_one_decision_per_slide_and_world():
     assert res[0] == want and res[1] == want, res
 
 
+def _verified_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    log = []
+    eng = _fake_auto(log)
+    res = []
+    for sid, n in ((1, 8), (2, 8), (1, 8), (2, 0 if rank == 0 else 8)):     # benign, hot on rank 1 only, benign, hot with an EMPTY shard on rank 0
+        slide = torch.zeros((4, 4, 3), dtype=torch.uint8)
+        slide[0, 0, 0], slide[0, 0, 1] = sid, rank
+        xy = torch.zeros((n, 2), dtype=torch.int32)
+        n0 = len(log)
+        out = eng.forward_tiles_verified(slide, xy, 256, 256, reduce_max=lambda e: S.allreduce_max(e, 'cpu', world))
+        res.append((eng.report['mode'], [(r[0], r[2]) for r in log[n0:]], tuple(out[1].shape), float(out[1].max()) if n else None))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_auto_precision_verified_after_the_forward():
+    """AutoTrunkEngine.forward_tiles_verified (r05, what slide.infer_slide_cls runs): the shard goes through mx first, the stratified sample
+    once more through parity, the sample errors are max-reduced over the ranks and only then is the mode fixed - mx logits stand where every
+    rank's sample agrees, otherwise EVERY rank runs its shard again in parity (also the one whose own sample was fine, and a rank without
+    tiles still takes part in the reduction)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verified_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    benign = ('mx', [('mx', 8), ('parity', 4)], (8, 4), 1.0)
+    for r in (0, 1):
+        assert res[r][0] == benign and res[r][2] == benign, res[r]
+        mode, calls, shape, mx = res[r][1]
+        assert mode == 'parity' and calls == [('mx', 8), ('parity', 4), ('parity', 8)] and shape == (8, 4) and mx == 1.0, res[r][1]   # parity logits returned
+    assert res[0][3] == ('parity', [], (0, 4), None), res[0][3]                         # no tiles, same decision, nothing to run
+    assert res[1][3] == ('parity', [('mx', 8), ('parity', 4), ('parity', 8)], (8, 4), 1.0), res[1][3]
+
+
 def test_auto_precision_does_not_trust_a_recycled_address():
     """Direct forward_tiles callers: a new slide tensor is a new slide even when the allocator hands it the old block (same
     data_ptr, same shape) - the engine keys on the tensor object or on a caller-supplied slide_id, never on the address."""

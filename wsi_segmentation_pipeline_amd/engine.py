@@ -446,6 +446,38 @@ class AutoTrunkEngine:
                        'reason': '%s = %.2e %s tol %.1e on %d stratified probe images' %
                                  (getattr(self, '_what', 'probe error'), err, '<=' if ok else '>', self.tol, getattr(self, '_n', 0))}
 
+    def forward_tiles_verified(self, slide_u8, tile_xy, ph, pw, reduce_max=None):
+        """One slide (or one rank's shard of it), mx FIRST and checked afterwards: the whole tile list runs in mx, the stratified sample of
+        probe_tiles once more in parity, and max |logit_mx - logit_parity| on the sample - reduced over the ranks by `reduce_max` (a
+        collective: every rank must call, shards without tiles contribute 0) - decides whether the mx logits stand or the list is run
+        again in parity.  Same sample, same rule and same report as probe_tiles + decide, but the mx forward of the sample and the host
+        synchronisation BEFORE the slide's main pass are gone (r05: the drop-in API ran 3-4 % behind the bare engine); the price is a
+        second pass over the slide in the rare case the answer is 'parity'.  Needs a head (logits).  Returns (feat=None, logits, None)."""
+        n = int(tile_xy.shape[0])
+        if self._mx is None:                                  # (the static weight check refused mx: report says why)
+            if reduce_max is not None:
+                reduce_max(0.0)                               # the other ranks' collective
+            self.report['order'] = 'parity only'
+            return self._par.forward_tiles(slide_u8, tile_xy, ph, pw, logits=True) if n else \
+                (None, torch.zeros((0, self.head_k), dtype=torch.float32, device=tile_xy.device), None)
+        out = self._mx.forward_tiles(slide_u8, tile_xy, ph, pw, logits=True) if n else None
+        err, nprobe = 0.0, 0
+        if n:
+            idx = self._stratified(n)
+            lp = self._par.forward_tiles(slide_u8, tile_xy[idx].contiguous(), ph, pw, logits=True)[1]
+            err, nprobe = float((out[1][idx] - lp).abs().max()), int(idx.shape[0])
+        if reduce_max is not None:
+            err = float(reduce_max(err))
+        self._what, self._n = 'max |logit_mx - logit_parity|', nprobe
+        self._probed = None
+        self.decide(err)
+        self.report['order'] = 'mx first, verified on the sample afterwards'
+        if self._chosen is self._par and n:
+            out = self._par.forward_tiles(slide_u8, tile_xy, ph, pw, logits=True)
+        if out is None:
+            out = (None, torch.zeros((0, self.head_k), dtype=torch.float32, device=tile_xy.device), None)
+        return out
+
     def forward_f32(self, x, feat=False, logits=False, fmap=False, tap=None):
         if self._chosen is None:
             self.decide(self.probe_f32(x), scope='head')

@@ -467,7 +467,12 @@ def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classe
     xy_dev = _upload(tile_xy[lo:hi] if local_xy is None else local_xy, torch.int32, dev)
     precision = None
     fwd_kw = {}
-    if hasattr(eng, 'probe_tiles'):
+    if hasattr(eng, 'forward_tiles_verified') and getattr(eng, 'head_k', 0):
+        # precision='auto', r05: mx first, verified afterwards on the stratified sample (AutoTrunkEngine.forward_tiles_verified) - ONE
+        # decision per slide for every rank (the sample errors are max-reduced before the decision; ranks without tiles take part)
+        _, logits, _ = eng.forward_tiles_verified(slide_level_dev, xy_dev, ph, pw, reduce_max=lambda e: allreduce_max(e, dev, world))
+        precision = dict(eng.report)
+    elif hasattr(eng, 'probe_tiles'):
         # precision='auto': ONE mode per slide for every rank - stratified probe of this rank's shard, maximum over the ranks.
         # The probe, the decision and the forward are tied together by an explicit slide id (a token of this call), not by the
         # identity of the tensor object: a caller's fresh view of the same level (`level[...]`, `.contiguous()`) must not make
@@ -475,7 +480,9 @@ def infer_slide_cls(eng, slide_level_dev, tile_xy, ph, pw, m, map_hw, num_classe
         fwd_kw['slide_id'] = object()
         eng.decide(allreduce_max(eng.probe_tiles(slide_level_dev, xy_dev, ph, pw, **fwd_kw), dev, world))
         precision = dict(eng.report)
-    if hi > lo:
+    if precision is not None and 'order' in precision:
+        pass                                                  # (forward_tiles_verified ran the shard)
+    elif hi > lo:
         _, logits, _ = eng.forward_tiles(slide_level_dev, xy_dev, ph, pw, logits=True, **fwd_kw)
     else:
         logits = torch.zeros((0, num_classes), dtype=torch.float32, device=dev)
