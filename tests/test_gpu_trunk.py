@@ -73,7 +73,7 @@ def test_u8_slide_path_equals_f32_path(dev, sd):
             native.check(lib.wsi_stem_set_mode(2, 32), 'stem mode')
             a_lut = eng.forward_tiles(sl, xyd, 64, 64, feat=True, logits=False)[0].clone()
         finally:
-            lib.wsi_stem_set_mode(1, 32)
+            lib.wsi_stem_set_mode(1, 64)
         if planes == 2:
             assert torch.equal(a_lut, b)
         scale = float(b.abs().max())
@@ -207,7 +207,7 @@ def test_unfused_reference_kernels_agree(dev, sd):
         native.check(lib.wsi_conv_set_mode(0), 'conv mode')
         alt = eng.forward_f32(x, logits=True)[1].clone()
     finally:
-        lib.wsi_stem_set_mode(1, 32)
+        lib.wsi_stem_set_mode(1, 64)
         lib.wsi_conv_set_mode(1)
     assert float((alt - base).abs().max()) <= 1e-4
 
@@ -232,7 +232,7 @@ def test_integer_stem_forms_bit_identical(dev, sd):
                     native.check(lib.wsi_stem_set_mode(3, rows), 'stem mode')
                     b = eng.forward_tiles(slide, xy, tile, tile, logits=False, tap=0).clone()
                 finally:
-                    lib.wsi_stem_set_mode(1, 32)
+                    lib.wsi_stem_set_mode(1, 64)
                 assert torch.equal(a, b), (planes, tile, n, rows)
 
 

@@ -351,7 +351,7 @@ int wsi_normalize_u8_lut(const float mean[3], const float std_[3], float* lut_ou
 }
 
 // ------------------------------------------------------------------------------------ single ops
-static int g_stem_fused = 1, g_stem_rows = 32;       // fused stem+maxpool kernel; pooled rows per workgroup
+static int g_stem_fused = 1, g_stem_rows = 64;       // fused stem+maxpool kernel; pooled rows per workgroup (r05 sweep: 16 / 32 / 64 -> 6.41 / 6.16 / 6.08 ms per 6 162 tiles)
 extern int g_stem_shared_weights;                     // stem.hip
 static int g_stem_u8x = 1;                            // exact-u8 arithmetic when the caller supplies its weights (A/B: fused = 2 disables)
 
