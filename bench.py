@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument('--no-prof', action='store_true', help='disable per-launch HIP events (roofline leg)')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the single-pass bf16 timing of the dominant kernel')
     ap.add_argument('--no-parity-leg', action='store_true', help='skip the parity-mode leg after the timed region')
-    ap.add_argument('--no-api-leg', action='store_true', help="skip the `api` leg (cfg3, one GPU): the same slide through the reference-named drop-in API with ITS defaults")
+    ap.add_argument('--no-api-leg', action='store_true', help="skip the `api` leg (cfg3 / seg, one GPU): the same slide through the reference-named drop-in API with ITS defaults")
     return ap.parse_args()
 
 
@@ -617,6 +617,84 @@ def run_rank(args):
                                   'note': 'save=True (the reference default): + the heat-map and overlay PNG files of the 2500 x 2500 map, host-side PIL'},
                'heatmap_equals_timed_region': same}
         del model, net, head
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and args.workload == 'seg' and not args.no_api_leg:
+        # The dense path through the reference-named API: utils.eval.predict_tumorbed(model, dataset, ep, mode='seg') with the model a
+        # UNetSeg (the smp.Unet drop-in) over a utils.dataset.Dataset_wsis of the SAME slide (/root/reference/utils/eval.py:196-215).
+        # r05: that call takes the engine's fused tile path (utils.eval._dense_batches); `generic_iterator_path` times the loop the
+        # reference writes - model.decoder(model.encoder(batch_image)) over the iterator's batches of myargs.batch_size tiles - on the
+        # same kernels, by hiding the model's type from the dispatch.
+        import tempfile
+        import myargs
+        import utils.dataset as UD
+        import utils.eval as UE
+        from PIL import Image
+        from wsi_segmentation_pipeline_amd.unet import UNetSeg
+        ts_ref = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            ts_ref.append(time.perf_counter() - r0)
+        t_ref = float(np.median(ts_ref[1:]))
+        model = UNetSeg(4, precision=args.mode)
+        model.load_state_dict(usd)
+        model = model.to(dev).eval()
+        model.hip_engine(dev).max_batch = args.seg_batch
+
+        class _Opaque(torch.nn.Module):                      # same kernels, but not a UNetSeg: the generic iterator loop
+            def __init__(self, u):
+                super().__init__()
+                self.encoder, self.decoder = u.encoder, u.decoder
+        ma = myargs.args
+        saved = {k: getattr(ma, k) for k in ('scan_level', 'scan_resize', 'num_classes', 'class_probs', 'tile_w', 'tile_h', 'tile_stride_w',
+                                             'tile_stride_h', 'wsi_mask_pth', 'val_save_pth')}
+        n_side = side * TILE
+        with tempfile.TemporaryDirectory() as td:
+            ma.scan_level, ma.scan_resize, ma.num_classes, ma.class_probs = 0, 1, 4, [0., 0., 0., 0.]
+            ma.tile_w = ma.tile_h = ma.tile_stride_w = ma.tile_stride_h = TILE
+            ma.wsi_mask_pth, ma.val_save_pth = td, os.path.join(td, 'out')
+            Image.fromarray(np.ones((n_side, n_side), np.uint8)).save(os.path.join(td, 'bench.svs.png'))
+
+            def make_dataset():
+                sl = S.ArraySlide([level0], [1.0])           # one level: the map is stitched at the scan level (m = 1)
+                sl.level_dimensions = ((n_side, n_side),)
+                sl.name = 'bench.svs'
+                return UD.Dataset_wsis({'bench.svs': sl}, {'ph': TILE, 'pw': TILE, 'sh': TILE, 'sw': TILE}, bs=ma.batch_size)
+
+            def timed(mdl, reps):
+                ts_ = []
+                for rep in range(reps + 1):                  # first call: warm-up (plans the workspaces)
+                    dsw_ = make_dataset()
+                    n_ = len(dsw_.wsis['bench.svs']['iterator'].dataset)
+                    torch.cuda.synchronize()
+                    a0 = time.perf_counter()
+                    res_ = UE.predict_tumorbed(mdl, dsw_, 0, mode='seg', save=False)['bench.svs']
+                    torch.cuda.synchronize()
+                    ts_.append(time.perf_counter() - a0)
+                return float(np.median(ts_[1:])), res_, n_
+            t_api, res, n_api = timed(model, 3)
+            t_gen, res_gen, _ = timed(_Opaque(model), 1)
+        for k, v in saved.items():
+            setattr(ma, k, v)
+        api = {'value': round(n_api / t_api, 1), 'unit': unit, 'ms_per_slide': round(t_api * 1e3, 3), 'tiles': n_api,
+               'vs_headline': round(n_api / t_api / value, 4),
+               'bare_engine_one_slide_per_call': {'value': round(args.seg_tiles / t_ref, 1), 'ms_per_slide': round(t_ref * 1e3, 3), 'tiles': args.seg_tiles,
+                                                  'note': 'UNetEngine.forward_tiles of the timed region (logits only: no stitch, no softmax, no maps to the host), one call + one '
+                                                          'synchronisation per slide, right before the API calls (median of 3 after one warm-up)'},
+               'vs_bare_engine_one_slide_per_call': round((n_api / t_api) / (args.seg_tiles / t_ref), 4),
+               'call': "utils.eval.predict_tumorbed(UNetSeg(4, precision=%r), utils.dataset.Dataset_wsis(...), ep, mode='seg', save=False)" % args.mode,
+               'timed': 'after the timed region: median of 3 calls after one warm-up call; includes the mask upload, the float64 dense stitch of every '
+                        '(4, 256, 256) block, the exponent-span guard, softmax + threshold + argmax on the %d x %d map, u8 maps to the host' % (n_side, n_side),
+               'generic_iterator_path': {'value': round(n_api / t_gen, 1), 'ms_per_slide': round(t_gen * 1e3, 3),
+                                         'note': 'the loop as the reference writes it: model.decoder(model.encoder(batch_image)) per iterator batch of %d tiles '
+                                                 '(myargs.batch_size), fp32 batches and fp32 encoder maps between the two calls; one call after a warm-up' % ma.batch_size,
+                                         'class_map_pixels_differing_from_fused_path': round(float((res_gen['classes'] != res['classes']).mean()), 6),
+                                         'why_not_zero': 'the generic loop feeds normalised fp32 tiles (split into the kernel format), the fused path the integer stem on u8 pixels: '
+                                                         'logits differ inside the 1e-3 contract, near-ties of the arg-max flip'}}
+        del model
         torch.cuda.empty_cache()
 
     if args.workload == 'seg' and rank == 0:

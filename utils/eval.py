@@ -83,6 +83,30 @@ def _save_png(arr, path):
     Image.fromarray(arr).save(path)
 
 
+def _dense_batches(model, it, scan, dev, forward):
+    """(xy (B,2) int ndarray, logits (B,C,ph,pw)) per batch of a dense (per-pixel) model over a slide's tile iterator.
+    Fused fast path (r05) when the model is this repo's UNetSeg and the tiles are read at the scan level's own resolution: the
+    U-Net engine reads the tiles straight from the HBM-resident level (integer stem on the u8 pixels, no normalised fp32 batch,
+    no fp32 round trip of the five encoder maps between `encoder` and `decoder`) in ITS batch size - the reference's
+    `batch_size` flag (30 tiles, myargs.py) leaves the chip mostly idle.  Any other model, a resized scan or a host iterator:
+    `forward(batch_image)` over the iterator, as the reference writes it (utils/eval.py:52-60, :196-215)."""
+    from wsi_segmentation_pipeline_amd.unet import UNetSeg
+    ds = getattr(it, 'dataset', None)
+    if isinstance(model, UNetSeg) and args.scan_resize == 1 and hasattr(it, 'span') and hasattr(scan, 'device_level'):
+        eng = model.hip_engine(dev)
+        level = scan.device_level(args.scan_level, dev)
+        lo, hi = it.span
+        ph, pw = ds.params.ph, ds.params.pw
+        nb = max(1, -(-(hi - lo) // eng._batch(ph, pw)))
+        mb = -(-(hi - lo) // nb)                             # equal batches: no short last batch (528 tiles: 5 x 106, not 4 x 128 + 16)
+        xy_dev = S._upload(ds.tile_xy[lo:hi], torch.int32, dev)     # one asynchronous upload: the host keeps enqueuing batches ahead of the GPU
+        for i in range(0, hi - lo, mb):
+            yield np.ascontiguousarray(ds.tile_xy[lo + i:min(lo + i + mb, hi)]), eng.forward_tiles(level, xy_dev[i:i + mb], ph, pw)
+        return
+    for batch_x, batch_y, batch_image in it:
+        yield np.stack((batch_x.numpy(), batch_y.numpy()), 1), forward(batch_image.to(dev))
+
+
 def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True):
     """Tumour-bed heat maps for every slide in ``dataset`` (a utils.dataset.Dataset_wsis).
     Writes <val_save_pth>/<ep>/<key>_<stride>_heatmap.png and _overlay.png (rank 0) and returns
@@ -138,17 +162,16 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                     my_it = it.shard(lo, hi)
                 span_lo, span_hi = None, None                 # exponent range of every addend: the exactness guard of the float64 sums
                 my_txy = []
-                for batch_x, batch_y, batch_image in my_it:
-                    pred_src = model.decoder(model.encoder(batch_image.to(dev)))
+
+                for xy, pred_src in _dense_batches(model, my_it, scan, dev, lambda x: model.decoder(model.encoder(x))):
                     if args.scan_resize != 1:
                         pred_src = E.resize_nearest(pred_src, (int(args.tile_h * args.scan_resize), int(args.tile_w * args.scan_resize)))
                     if tuple(pred_src.shape[2:]) != (dy, dx):
                         raise ValueError("mode='seg': the decoder output %s does not match the stitch footprint (%d, %d) = int(m * tile); "
                                          "scan at the map's level or set scan_resize (utils/eval.py:202-215)" % (tuple(pred_src.shape[2:]), dy, dx))
-                    xy = np.stack((batch_x.numpy(), batch_y.numpy()), 1)
                     txy = S.map_coords(xy, m)
                     my_txy.append(np.asarray(txy))
-                    E.stitch_add_dense(pred, pred_src, torch.from_numpy(txy))
+                    E.stitch_add_dense(pred, pred_src, S._upload(txy, torch.int32, dev))      # (pinned + asynchronous: a pageable copy blocks the host)
                     sp = E.exponent_span(pred_src)
                     span_lo = sp[0:1] if span_lo is None else torch.minimum(span_lo, sp[0:1])
                     span_hi = sp[1:2] if span_hi is None else torch.maximum(span_hi, sp[1:2])
@@ -224,12 +247,10 @@ def predict_wsis(model, dataset, ep, save=True):
             ds, scan = it.dataset, entry['scan']
             iw, ih = scan.level_dimensions[args.scan_level]
             pred = torch.zeros((args.num_classes, ih, iw), dtype=torch.float64, device=dev)
-            for batch_x, batch_y, batch_image in it:
-                pred_src = model(batch_image.to(dev))
+            for xy, pred_src in _dense_batches(model, it, scan, dev, model):
                 if pred_src.dim() != 4 or pred_src.shape[1] != args.num_classes:
                     raise ValueError('predict_wsis needs a dense model returning (B, %d, ph, pw)' % args.num_classes)
-                xy = torch.stack((batch_x, batch_y), 1).to(torch.int32)        # int(batch_x[bj]): truncation
-                E.stitch_add_dense(pred, pred_src, xy)
+                E.stitch_add_dense(pred, pred_src, S._upload(xy, torch.int32, dev))        # int(batch_x[bj]): truncation
             classes = PP.argmax_classes(pred)
             ref_level = min(2, len(scan.level_dimensions) - 1)
             map_hw = tuple(scan.level_dimensions[ref_level][::-1])

@@ -170,8 +170,9 @@ class UNetEngine:
         _require_gpu(slide_u8, 'slide')
         tile_xy = tile_xy.to(self.device, torch.int32).contiguous()
         n = tile_xy.shape[0]
-        mb = self._batch(ph, pw)
-        return torch.cat([self._run(min(mb, n - i), ph, pw, None, slide_u8, tile_xy[i:i + mb], True, False)[0] for i in range(0, n, mb)])
+        mb = -(-n // max(1, -(-n // self._batch(ph, pw))))    # equal batches: no short last one
+        parts = [self._run(min(mb, n - i), ph, pw, None, slide_u8, tile_xy[i:i + mb], True, False)[0] for i in range(0, n, mb)]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
 
     def decode(self, enc):
         """`model.decoder(encoding)`: five fp32 NCHW GPU maps (deepest first) -> logits."""
