@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WSI_HIP_ABI_VERSION 5            /* r05: planes 2 = fp16 pair, its packed conv weights end in cout inverse channel scales */
+#define WSI_HIP_ABI_VERSION 6            /* r05: planes 2 = fp16 pair, its packed conv weights end in cout inverse channel scales; wsi_unet_decoder_weights.tail_w */
 int wsi_hip_abi_version(void);
 
 /* ---- padded-flat layout helpers (host) -------------------------------------------------------
@@ -138,7 +138,9 @@ int wsi_conv3x3s2_ds_fused_split(const void* in_split, void* out_conv_pf, void* 
  * U-Net decoder blocks write the upsampled + concatenated tensor before their first conv instead of reading both sources in it
  * (bit-identical), +131072 the wide stride-1 kernel keeps the 9-pixel slab pitch on 8 x 8 maps (r05 default: 8-pixel slab rows, no LDS
  * bank conflicts; bit-identical), +1048576 the 64-channel layer 1 on the persistent producer-fed kernel (r05 study route: bit-identical,
- * measured 30-45 % slower than the row-stacked kernel).  Process-wide. */
+ * measured 30-45 % slower than the row-stacked kernel), +2097152 the U-Net decoder's last block and head as three launches even when
+ * the fused-tail weights are present (planes 2; results equal to fp32 rounding of the summed polyphase weights, not bit-identical).
+ * Process-wide. */
 int wsi_conv_set_mode(int s2_slab);
 /* tuning hook: same as wsi_conv3x3_bn_act with an explicit tile configuration for the stride-1
  * kernel (cfg index into the table in csrc/conv.hip; -1 = tuned default; -22 if not applicable) */
@@ -362,7 +364,18 @@ typedef struct {
     int cin[10], cout[10];
     const float* head_w; const float* head_b;
     int head_cin, classes;
+    const void* tail_w;          /* device copy of wsi_unet_tail_prepack's blob, or NULL: the fused last block + head (planes 2) */
 } wsi_unet_decoder_weights;
+/* r05, planes 2: the LAST decoder block (upsample, two 3x3 conv + BN + ReLU at full resolution) and the 1x1 head as ONE kernel
+ * (csrc/tail.hip: the conv on the upsampled map as a polyphase filter on the low-resolution rows, both intermediate tensors kept in
+ * LDS).  w1 [cmid][cin][3][3], w2 [cmid][cmid][3][3] fp32 with their BatchNorm vectors, head_w [classes][cmid], head_b [classes];
+ * cin = 32, cmid <= 16, classes <= 4.  `out` = wsi_unet_tail_prepack_bytes() bytes of host memory; copy it to the device and store the
+ * pointer in wsi_unet_decoder_weights.tail_w.  The three-launch path stays in force when tail_w is NULL, in the other precision
+ * modes and for maps wider than 256. */
+size_t wsi_unet_tail_prepack_bytes(void);
+int wsi_unet_tail_prepack(const float* w1, const float* bn1_weight, const float* bn1_bias, const float* bn1_mean, const float* bn1_var,
+                          const float* w2, const float* bn2_weight, const float* bn2_bias, const float* bn2_mean, const float* bn2_var,
+                          float eps, const float* head_w, const float* head_b, int cin, int cmid, int classes, void* out);
 size_t wsi_unet_workspace_bytes(const wsi_unet_decoder_weights* dw, int n, int h, int w, int planes);
 int wsi_unet_workspace_init(const wsi_unet_decoder_weights* dw, void* workspace, int n, int h, int w, int planes, void* stream);
 int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights* dw, const float* in_f32, const uint8_t* slide,

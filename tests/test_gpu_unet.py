@@ -216,3 +216,39 @@ def test_fused_upsample_concat_conv_is_bit_identical(dev, shape):
         assert float((got.cpu() - want).abs().max() / want.abs().max()) <= (2e-3 if planes == 3 else 2e-4)
         ran += 1
     assert ran == 2
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64), (2, 128, 192), (1, 256, 256), (5, 96, 128), (2, 64, 96)])
+def test_fused_decoder_tail_agrees_with_the_three_launch_path_and_the_spec(dev, sd, shape):
+    """r05 (csrc/tail.hip): parity mode runs the LAST decoder block and the 1x1 head as one kernel - the 3x3 conv on the upsampled map as
+    a polyphase filter with host-summed weights, both intermediate tensors in LDS.  Against the three-launch path (A/B switch
+    wsi_conv_set_mode +2097152) the logits differ by the fp32 rounding of the summed weights only; against the fp32 spec both hold the
+    absolute 1e-3 contract at |logit| 16.  Shapes: one / several bands per image (a 256-row image of a small batch splits into 16 bands:
+    every band seam recomputes its neighbours' conv1 rows), maps 64 to 256 wide (2 to 8 waves per workgroup), and a width whose half is
+    not a multiple of 32 (96: the tail is refused, the three launches run - bit-identical)."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.unet import UNetEngine
+    n, h, w = shape
+    lib = native.load()
+    u8 = W.make_u8_patches(90 + h + w, (n, 3, h, w))
+    x = R.normalize_u8(u8)
+    sd = _scaled_to_logit(sd, x[:1] if h * w > 128 * 192 else x)
+    eng = UNetEngine(sd, dev, planes=2)
+    assert eng.dw.tail_w
+    fused = eng.forward_f32(x.to(dev))[0]
+    lib.wsi_conv_set_mode(1 + 2097152)
+    try:
+        plain = eng.forward_f32(x.to(dev))[0]
+    finally:
+        lib.wsi_conv_set_mode(1)
+    assert torch.isfinite(fused).all()
+    d = float((fused - plain).abs().max())
+    scale = float(plain.abs().max())
+    print('fused tail vs three launches %s: max |dlogit| %.3g at max |logit| %.3g' % (shape, d, scale))
+    if (w // 2) % 32:
+        assert torch.equal(fused, plain)
+        return
+    assert 0 < d <= 2e-5 * max(scale, 1.0)                                # another rounding of the same conv, not the same bits
+    with torch.no_grad():
+        ref = U.unet_forward(sd, x[:1])
+    assert float((fused[:1].cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()) / 16.0)

@@ -42,6 +42,7 @@ int wsi_softmax_dispatch(const double* pred, int C, long long HW, const double* 
 
 int wsi_upsample_concat_dispatch(const void* x, const void* skip, void* out, int n, int h, int w, int cx, int cs, int planes, hipStream_t st);
 int wsi_nhwc_to_pf_dispatch(const float* in, void* out, int n, int h, int w, int c, int planes, hipStream_t st);
+int wsi_unet_tail_dispatch(const void* x4, const void* blob, int n, int h, int w, int classes, float* logits, hipStream_t st);
 int wsi_unet_head_dispatch(const void* in, int n, int h, int w, int c_pf, const float* wt, const float* b, int cin, int k, float* out,
                            int planes, hipStream_t st);
 int wsi_resize_nearest_dispatch(const float* src, long long planes_n, int hs, int ws, float* dst, int hd, int wd, hipStream_t st);
@@ -245,6 +246,121 @@ int wsi_prepack_conv(const float* w, const float* bn_weight, const float* bn_bia
                         }
                     }
                 }
+    return WSI_OK;
+}
+
+// Weights of the fused decoder tail (tail.hip): the last decoder block's two 3x3 convs (BN folded) and the 1x1 head, parity mode.
+//   conv1 [2 py][6 taps = 2 low rows x 3 low columns][4 fragments] x 1 KiB: A rows 0-15 = output channels at px = 0, rows 16-31 at px = 1;
+//         the weight of low-resolution offset (oy, ox) = the float64 SUM of the 3x3 taps whose upsampled source falls on it
+//         (py = 0: dy 0 -> oy -1, dy 1, 2 -> oy 0; py = 1: dy 0, 1 -> oy 0, dy 2 -> oy +1; columns alike), rounded to fp32
+//   conv2 [12 taps = 4 input rows x 3 columns][hi, lo] x 1 KiB: A rows 0-15 = output row 2k - 1 (dy = input row), rows 16-31 = row 2k
+//         (dy = input row - 1), K = the 16 channels
+//   then fp32: 1 / scale of conv1 [16], bias1 [16], 1 / scale of conv2 [16], bias2 [16], head_w [4][16] (zero padded), head_b [4]
+// Every output channel's weights carry a power-of-two scale that puts its largest magnitude into [2^13, 2^14) (as wsi_prepack_conv).
+size_t wsi_unet_tail_prepack_bytes(void) { return (size_t)(2 * 6 * 4 + 12 * 2) * 1024 + 132 * sizeof(float); }
+
+int wsi_unet_tail_prepack(const float* w1, const float* bn1_weight, const float* bn1_bias, const float* bn1_mean, const float* bn1_var,
+                          const float* w2, const float* bn2_weight, const float* bn2_bias, const float* bn2_mean, const float* bn2_var,
+                          float eps, const float* head_w, const float* head_b, int cin, int cmid, int classes, void* out) {
+    if (!w1 || !w2 || !head_w || !out || cin != 32 || cmid < 1 || cmid > 16 || classes < 1 || classes > 4) return WSI_EINVAL;
+    memset(out, 0, wsi_unet_tail_prepack_bytes());
+    uint16_t* o1 = (uint16_t*)out;
+    uint16_t* o2 = (uint16_t*)((char*)out + 2 * 6 * 4 * 1024);
+    float* fl = (float*)((char*)out + (2 * 6 * 4 + 12 * 2) * 1024);
+    auto scale_of = [](float amax, float& mul, float& inv) {
+        int e = 0;
+        if (amax > 0.f && std::isfinite(amax)) {
+            frexpf(amax, &e);
+            e = 14 - e;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        mul = ldexpf(1.0f, e);
+        inv = ldexpf(1.0f, -e);
+    };
+    // conv1: combined (polyphase) weights wc[py][a][oxi][px][c][ci]
+    static const int lo_set[2][2][3] = {{{1, 0, 0}, {0, 1, 1}}, {{1, 1, 0}, {0, 0, 1}}};     // [parity][first / second low offset][d] -> d contributes
+    std::vector<float> wc((size_t)2 * 2 * 3 * 2 * 16 * 32, 0.f);
+    auto WC = [&](int py, int a_, int oxi, int px, int c, int ci) -> float& { return wc[(((((size_t)py * 2 + a_) * 3 + oxi) * 2 + px) * 16 + c) * 32 + ci]; };
+    for (int c = 0; c < cmid; ++c) {
+        double sc, sh;
+        bn_fold(bn1_weight, bn1_bias, bn1_mean, bn1_var, eps, c, sc, sh);
+        fl[16 + c] = (float)sh;
+        float amax = 0.f;
+        for (int py = 0; py < 2; ++py)
+            for (int a_ = 0; a_ < 2; ++a_)
+                for (int px = 0; px < 2; ++px)
+                    for (int b_ = 0; b_ < 2; ++b_) {
+                        const int oxi = px + b_;                                          // px = 0: offsets -1, 0; px = 1: offsets 0, +1
+                        for (int ci = 0; ci < 32; ++ci) {
+                            double sum = 0.0;
+                            for (int dy = 0; dy < 3; ++dy)
+                                for (int dx = 0; dx < 3; ++dx)
+                                    if (lo_set[py][a_][dy] && lo_set[px][b_][dx])
+                                        sum += (double)(float)((double)w1[(((size_t)c * cin + ci) * 3 + dy) * 3 + dx] * sc);
+                            const float v = (float)sum;
+                            WC(py, a_, oxi, px, c, ci) = v;
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                    }
+        float mul, inv;
+        scale_of(amax, mul, inv);
+        fl[c] = inv;
+        for (int py = 0; py < 2; ++py)
+            for (int a_ = 0; a_ < 2; ++a_)
+                for (int oxi = 0; oxi < 3; ++oxi)
+                    for (int px = 0; px < 2; ++px)
+                        for (int ci = 0; ci < 32; ++ci) WC(py, a_, oxi, px, c, ci) *= mul;
+    }
+    for (int py = 0; py < 2; ++py)
+        for (int t = 0; t < 6; ++t)
+            for (int f = 0; f < 4; ++f) {
+                uint16_t* frag = o1 + (size_t)((py * 6 + t) * 4 + f) * 512;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = lane & 31, px = row >> 4, c = row & 15;
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = 16 * (f & 1) + 8 * (lane >> 5) + j;
+                        uint16_t hi, lo;
+                        split_host_f16(WC(py, t / 3, t % 3, px, c, ci), hi, lo);
+                        frag[lane * 8 + j] = (f >> 1) ? lo : hi;
+                    }
+                }
+            }
+    // conv2
+    std::vector<float> w2s((size_t)16 * 16 * 9, 0.f);
+    for (int c = 0; c < cmid; ++c) {
+        double sc, sh;
+        bn_fold(bn2_weight, bn2_bias, bn2_mean, bn2_var, eps, c, sc, sh);
+        fl[48 + c] = (float)sh;
+        float amax = 0.f;
+        for (int ci = 0; ci < cmid; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const float v = (float)((double)w2[((size_t)c * cmid + ci) * 9 + t] * sc);
+                w2s[((size_t)c * 16 + ci) * 9 + t] = v;
+                amax = fmaxf(amax, fabsf(v));
+            }
+        float mul, inv;
+        scale_of(amax, mul, inv);
+        fl[32 + c] = inv;
+        for (int ci = 0; ci < 16; ++ci)
+            for (int t = 0; t < 9; ++t) w2s[((size_t)c * 16 + ci) * 9 + t] *= mul;
+    }
+    for (int t = 0; t < 12; ++t)
+        for (int p = 0; p < 2; ++p) {
+            uint16_t* frag = o2 + (size_t)(t * 2 + p) * 512;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 31, rs = row >> 4, c = row & 15, dy = t / 3 - rs, dx = t % 3;
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = 8 * (lane >> 5) + j;
+                    uint16_t hi, lo;
+                    split_host_f16((dy >= 0 && dy <= 2) ? w2s[((size_t)c * 16 + ci) * 9 + dy * 3 + dx] : 0.f, hi, lo);
+                    frag[lane * 8 + j] = p ? lo : hi;
+                }
+            }
+        }
+    for (int k = 0; k < classes; ++k) {
+        for (int c = 0; c < cmid; ++c) fl[64 + k * 16 + c] = head_w[(size_t)k * cmid + c];
+        fl[128 + k] = head_b ? head_b[k] : 0.f;
+    }
     return WSI_OK;
 }
 
@@ -541,12 +657,14 @@ int wsi_conv3x3s2_ds_fused(const void* in_pf, void* out_conv_pf, void* out_ds_pf
 extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_ranges, g_slab_pair;
 extern int g_l1_lines96, g_s2_nt4, g_l1_rows, g_wide_d8, g_l1p;
 extern int g_unet_fuse_up;
+extern int g_unet_tail;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
     g_ds_fold = (s2_slab & 2048) ? 0 : 1;
     g_slab_pair = (s2_slab & 4096) ? 0 : 1;
     g_l1_rows = (s2_slab & 1024) ? 0 : 1;
     g_unet_fuse_up = (s2_slab & 65536) ? 0 : 1;
+    g_unet_tail = (s2_slab & 2097152) ? 0 : 1;
     g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_s2_nt4 = (s2_slab & 32768) ? 0 : 1;
     g_wide_d8 = (s2_slab & 131072) ? 0 : 1;
@@ -1086,6 +1204,7 @@ int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, cons
 // speed mode; the padding channels carry zero weights), 1x1 head.
 static const int kUnetSkipC[5] = {256, 128, 64, 64, 0};      // encoder maps x3, x2, x1, x0 (and none for the last block)
 int g_unet_fuse_up = 1;                                  // A/B: wsi_conv_set_mode +65536 off
+int g_unet_tail = 1;                                     // A/B: wsi_conv_set_mode +2097152 off
 struct UnetPlan {
     size_t x0, cat[5], mid[5], out[5], total;
     int r_h[5], r_w[5], cx[5];                               // resolution of block L; channels of its upsampled input
@@ -1131,7 +1250,11 @@ static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& 
     int rc = WSI_OK;
     // wsi_prof kinds of the decoder (bench.py --workload seg): 6 = decoder 3x3 conv (algorithmic FLOPs over REAL channels are the
     // caller's business: the record carries 2 * N * H * W * cin_stored * cout_stored * 9), 7 = upsample + concat glue, 8 = 1x1 head
-    for (int L = 0; L < 5 && !rc; ++L) {
+    // r05: parity mode runs the last block and the head as ONE kernel (tail.hip) when the caller prepacked its weights
+    // (wsi_unet_tail_prepack -> dw->tail_w) and the map is at most 256 wide; A/B: wsi_conv_set_mode +2097152 off
+    const bool tail = planes == 2 && dw->tail_w && g_unet_tail && u.cx[4] == 32 && kUnetSkipC[4] == 0 && dw->classes <= 4 &&
+                      u.r_w[3] % 32 == 0 && u.r_w[3] <= 128;
+    for (int L = 0; L < (tail ? 4 : 5) && !rc; ++L) {
         const int H = u.r_h[L], W = u.r_w[L], cin = dw->cin[2 * L], cout = dw->cout[2 * L];
         // r04: the block's first conv reads the low-resolution tensor and the skip directly (ConvArgs.in_up: nearest x2 upsample +
         // concat as source addresses of its slab DMA) where the shape's kernel is the slab3 kernel; otherwise (EINVAL) the
@@ -1154,6 +1277,13 @@ static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& 
         if (!rc) rc = conv_common(dec + u.mid[L], dec + u.out[L], nullptr, dw->conv_w[2 * L + 1], dw->conv_b[2 * L + 1], n, H, W, cout, cout, 1, 3, 1, planes, st);
         prof_close(st, pi);
         x = dec + u.out[L];
+    }
+    if (tail) {
+        // (kind 6: the decoder-conv record carries the unfused formulation's FLOPs over the stored channels, like the four blocks above)
+        const int pt = prof_open(st, 6, 2.0 * n * u.r_h[4] * u.r_w[4] * 9.0 * ((double)dw->cin[8] * dw->cout[8] + (double)dw->cin[9] * dw->cout[9]));
+        if (!rc) rc = wsi_unet_tail_dispatch(x, dw->tail_w, n, u.r_h[3], u.r_w[3], dw->classes, logits_out, st);
+        prof_close(st, pt);
+        return rc;
     }
     const int pi = prof_open(st, 8, 2.0 * n * u.r_h[4] * u.r_w[4] * (double)dw->head_cin * dw->classes);
     if (!rc) rc = wsi_unet_head_dispatch(x, n, u.r_h[4], u.r_w[4], dw->cout[9], dw->head_w, dw->head_b, dw->head_cin, dw->classes, logits_out, planes, st);

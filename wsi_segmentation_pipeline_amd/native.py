@@ -32,7 +32,7 @@ class WsiTrunkWeights(C.Structure):
 class WsiUnetDecoderWeights(C.Structure):
     _fields_ = [
         ('conv_w', C.c_void_p * 10), ('conv_b', C.c_void_p * 10), ('cin', C.c_int * 10), ('cout', C.c_int * 10),
-        ('head_w', C.c_void_p), ('head_b', C.c_void_p), ('head_cin', C.c_int), ('classes', C.c_int),
+        ('head_w', C.c_void_p), ('head_b', C.c_void_p), ('head_cin', C.c_int), ('classes', C.c_int), ('tail_w', C.c_void_p),
     ]
 
 
@@ -44,6 +44,8 @@ SIGNATURES = {
     'wsi_pf_pixel_index': (_ll, [_i, _i, _i, _i, _i]),
     'wsi_prepack_conv_bytes': (_sz, [_i, _i, _i, _i]),
     'wsi_prepack_conv': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
+    'wsi_unet_tail_prepack_bytes': (_sz, []),
+    'wsi_unet_tail_prepack': (_i, [_vp] * 10 + [_f, _vp, _vp, _i, _i, _i, _vp]),
     'wsi_prepack_stem_bytes': (_sz, [_i]),
     'wsi_prepack_stem': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     'wsi_prepack_stem_u8': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp]),
@@ -135,7 +137,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 5                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
+ABI_VERSION = 6                          # include/wsi_hip.h WSI_HIP_ABI_VERSION (tests/test_capi_symbols.py compares the two)
 
 
 def load():

@@ -105,6 +105,18 @@ class UNetEngine:
         self.dw.head_w = dev(np.ascontiguousarray(hw)).data_ptr()
         self.dw.head_b = dev(f32('decoder.final_conv.bias')).data_ptr()
         self.dw.head_cin, self.dw.classes = DEC_CH[4], self.classes
+        self.dw.tail_w = None
+        if planes == PARITY and DEC_CH[3] == 32 and DEC_CH[4] <= 16 and self.classes <= 4:
+            # r05: the last block + head as one kernel (csrc/tail.hip) on the block's REAL channels
+            p0, p1 = ('decoder.layer5.block.%d.block' % j for j in range(2))
+            bn = [[f32('%s.1.%s' % (p, sfx)) for sfx in ('weight', 'bias', 'running_mean', 'running_var')] for p in (p0, p1)]
+            blob = np.empty(self.lib.wsi_unet_tail_prepack_bytes(), np.uint8)
+            hb = f32('decoder.final_conv.bias')
+            native.check(self.lib.wsi_unet_tail_prepack(_np_ptr(f32(p0 + '.0.weight')), *[_np_ptr(a) for a in bn[0]],
+                                                        _np_ptr(f32(p1 + '.0.weight')), *[_np_ptr(a) for a in bn[1]], BN_EPS,
+                                                        _np_ptr(np.ascontiguousarray(hw)), _np_ptr(hb), DEC_CH[3], DEC_CH[4], self.classes,
+                                                        _np_ptr(blob)), 'wsi_unet_tail_prepack')
+            self.dw.tail_w = dev(blob).data_ptr()
 
     def _workspace(self, n, h, w):
         key = (h, w)
