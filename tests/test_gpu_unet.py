@@ -236,11 +236,16 @@ def test_fused_decoder_tail_agrees_with_the_three_launch_path_and_the_spec(dev, 
     eng = UNetEngine(sd, dev, planes=2)
     assert eng.dw.tail_w
     fused = eng.forward_f32(x.to(dev))[0]
-    lib.wsi_conv_set_mode(1 + 2097152)
     try:
+        lib.wsi_conv_set_mode(1 + 4194304)                                # the first form of the kernel (all waves do both convs)
+        form1 = eng.forward_f32(x.to(dev))[0]
+        lib.wsi_conv_set_mode(1 + 2097152)
         plain = eng.forward_f32(x.to(dev))[0]
     finally:
         lib.wsi_conv_set_mode(1)
+    assert torch.equal(fused, eng.forward_f32(x.to(dev))[0])             # (the specialised form synchronises through an LDS counter: same bits every run)
+    d12 = float((fused - form1).abs().max())
+    assert d12 <= 2e-6 * max(float(plain.abs().max()), 1.0), d12          # same weights, same products; the head sums in another order
     assert torch.isfinite(fused).all()
     d = float((fused - plain).abs().max())
     scale = float(plain.abs().max())

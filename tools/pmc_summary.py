@@ -11,7 +11,7 @@ for path in sys.argv[1:]:
         key = (name, r.get('Grid_Size', ''), r.get('Workgroup_Size', ''))
         acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
 for key in sorted(acc):
-    if 'conv' not in key[0] and 'stem' not in key[0] and 'maxpool' not in key[0]:
+    if 'conv' not in key[0] and 'stem' not in key[0] and 'maxpool' not in key[0] and 'unet' not in key[0]:
         continue
     vals = {k: sum(v) / len(v) for k, v in acc[key].items()}
     print(key[0], 'grid', key[1], 'wg', key[2], 'n=%d' % len(next(iter(acc[key].values()))))

@@ -658,6 +658,7 @@ extern int g_s2_small_tiles, g_xcd_order, g_wide_min_c, g_s2_ablate, g_xcd_range
 extern int g_l1_lines96, g_s2_nt4, g_l1_rows, g_wide_d8, g_l1p;
 extern int g_unet_fuse_up;
 extern int g_unet_tail;
+extern int g_unet_tail_form;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
     g_ds_fold = (s2_slab & 2048) ? 0 : 1;
@@ -665,6 +666,7 @@ int wsi_conv_set_mode(int s2_slab) {
     g_l1_rows = (s2_slab & 1024) ? 0 : 1;
     g_unet_fuse_up = (s2_slab & 65536) ? 0 : 1;
     g_unet_tail = (s2_slab & 2097152) ? 0 : 1;
+    g_unet_tail_form = (s2_slab & 4194304) ? 1 : 2;
     g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_s2_nt4 = (s2_slab & 32768) ? 0 : 1;
     g_wide_d8 = (s2_slab & 131072) ? 0 : 1;
