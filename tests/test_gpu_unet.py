@@ -257,3 +257,35 @@ def test_fused_decoder_tail_agrees_with_the_three_launch_path_and_the_spec(dev, 
     with torch.no_grad():
         ref = U.unet_forward(sd, x[:1])
     assert float((fused[:1].cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()) / 16.0)
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64), (2, 128, 192), (3, 256, 256), (2, 96, 160)])
+def test_stem_kernel_stores_the_half_resolution_skip_itself(dev, sd, shape):
+    """r05: on the product path (tiles read from a u8 slide, parity mode) the fused stem + pool kernel also stores x0 = relu(bn1(conv1(x))),
+    the conv values it pools anyway (exact integer products), where r02-r04 ran a second, unfused fp16-pair stem conv for it
+    (A/B: wsi_conv_set_mode +8388608).  The logits of both routes agree to the pair's rounding and hold the contract against the spec;
+    shapes: one strip (64-wide: even lane layout), several strips and segments, odd strip counts, tiles reaching past the slide."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.unet import UNetEngine
+    n, h, w = shape
+    lib = native.load()
+    rng = np.random.default_rng(h + w)
+    slide_np = rng.integers(0, 256, (h + 40, 2 * w + 24, 3), dtype=np.uint8)
+    slide = torch.from_numpy(slide_np).to(dev)
+    xy = torch.tensor([[0, 0], [w + 30, 44], [7, 13]][:n], dtype=torch.int32)       # the second tile reaches 6 / 4 pixels past the slide
+    u8 = np.stack([WO.read_tile(slide_np, int(x), int(y), w, h) for x, y in xy]).transpose(0, 3, 1, 2)
+    x = R.normalize_u8(u8)
+    sd = _scaled_to_logit(sd, x[:1])
+    eng = UNetEngine(sd, dev, planes=2)
+    fused = eng.forward_tiles(slide, xy, h, w)
+    lib.wsi_conv_set_mode(1 + 8388608)
+    try:
+        plain = eng.forward_tiles(slide, xy, h, w)
+    finally:
+        lib.wsi_conv_set_mode(1)
+    d = float((fused - plain).abs().max())
+    print('x0 from the pool kernel vs the unfused stem conv %s: max |dlogit| %.3g' % (shape, d))
+    assert 0 < d <= 2e-4
+    with torch.no_grad():
+        ref = U.unet_forward(sd, x)
+    assert float((fused.cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()) / 16.0)

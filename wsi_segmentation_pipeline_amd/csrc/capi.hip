@@ -13,7 +13,7 @@ int wsi_conv_dispatch(const ConvArgs& a, int planes, int cfg, hipStream_t st);
 int wsi_s2_dispatch(const ConvArgs& a, int planes, hipStream_t st);
 int wsi_stem_dispatch(const StemArgs& a, int planes, hipStream_t st);
 int wsi_maxpool_dispatch(const float* in, void* out, int N, int Hc, int Wc, int planes, hipStream_t st);
-int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96 = 0, long long plane96 = 0);
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96 = 0, long long plane96 = 0, void* x0_pf = nullptr);
 int wsi_avgpool_fc_dispatch(const void* in, const PFGeom& g, const float* w, const float* b, int K, float* feat,
                             float* logits, int planes, hipStream_t st);
 int wsi_linear_dispatch(const float* x, const float* w, const float* bias, float* y, int B, int K, int J, int relu,
@@ -483,7 +483,7 @@ static int stem_run(const float* in_f32, const uint8_t* slide, long long slide_p
                     int slide_h, int slide_w, const int* tile_xy, const float* lut,
                     const void* stem_wpk, const float* stem_bias, const void* stem_wpk_u8,
                     const float* stem_bias_u8, const float* norm_mean_std, int n, int h, int w,
-                    float* scratch, void* out_pf, int planes, void* stream, int out96, long long plane96 = 0) {
+                    float* scratch, void* out_pf, int planes, void* stream, int out96, long long plane96 = 0, void* x0_pf = nullptr) {
     if (!stem_wpk || !stem_bias || !scratch || !out_pf || n <= 0 || h % 16 || w % 4) return WSI_EINVAL;
     if (!in_f32 && (!slide || !tile_xy || !lut)) return WSI_EINVAL;
     StemArgs a;
@@ -496,7 +496,8 @@ static int stem_run(const float* in_f32, const uint8_t* slide, long long slide_p
     // for ABI stability and as the caller's statement of which transform those weights carry)
     if (stem_wpk_u8 && stem_bias_u8 && norm_mean_std && !in_f32 && g_stem_u8x) { a.wpk_u8 = stem_wpk_u8; a.bias_u8 = stem_bias_u8; }
     if (out96 && planes != 3) return WSI_EINVAL;
-    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream, out96, plane96);
+    if (x0_pf && !(a.wpk_u8 && g_stem_fused && planes == 2)) return WSI_EINVAL;       // (the x0 output: integer fused stem, fp16-pair lines)
+    if (g_stem_fused || planes == 3) return wsi_stem_pool_dispatch(a, out_pf, planes, g_stem_rows, (hipStream_t)stream, out96, plane96, x0_pf);
     int rc = wsi_stem_dispatch(a, planes, (hipStream_t)stream);
     if (rc) return rc;
     return wsi_maxpool_dispatch(scratch, out_pf, n, h / 2, w / 2, planes, (hipStream_t)stream);
@@ -659,6 +660,7 @@ extern int g_l1_lines96, g_s2_nt4, g_l1_rows, g_wide_d8, g_l1p;
 extern int g_unet_fuse_up;
 extern int g_unet_tail;
 extern int g_unet_tail_form;
+extern int g_unet_x0_fused;
 int wsi_conv_set_mode(int s2_slab) {
     g_s2_split = (s2_slab & 128) ? 0 : 1;
     g_ds_fold = (s2_slab & 2048) ? 0 : 1;
@@ -667,6 +669,7 @@ int wsi_conv_set_mode(int s2_slab) {
     g_unet_fuse_up = (s2_slab & 65536) ? 0 : 1;
     g_unet_tail = (s2_slab & 2097152) ? 0 : 1;
     g_unet_tail_form = (s2_slab & 4194304) ? 1 : 2;
+    g_unet_x0_fused = (s2_slab & 8388608) ? 0 : 1;
     g_l1_lines96 = (s2_slab & 16384) ? 0 : 1;
     g_s2_nt4 = (s2_slab & 32768) ? 0 : 1;
     g_wide_d8 = (s2_slab & 131072) ? 0 : 1;
@@ -1002,7 +1005,7 @@ int wsi_trunk_workspace_init(void* workspace, int n, int h, int w, int planes, v
 static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uint8_t* slide, long long pitch, int slide_h,
                      int slide_w, const int* tile_xy, const float* lut, int n, int cap, int h, int w, void* workspace,
                      int stop_after, hipStream_t st, const TrunkPlan& p, size_t& last_off, int& last_stage,
-                     bool allow_split = true, size_t* stage_off = nullptr) {
+                     bool allow_split = true, size_t* stage_off = nullptr, char* x0_out = nullptr) {
     char* ws = (char*)workspace;
     const int planes = wt->planes;
     int rc = WSI_OK;
@@ -1056,7 +1059,8 @@ static int trunk_run(const wsi_trunk_weights* wt, const float* in_f32, const uin
                           slide_w, tile_xy ? tile_xy + 2 * n0 : nullptr, lut, wt->stem_w, wt->stem_b,
                           wt->stem_w_u8, wt->stem_b_u8, wt->norm,
                           nn, h, w, (float*)(ws + p.stem_scratch), ws + p.buf[0][0] + img_off(0, n0),
-                          planes, st, l96 ? 1 : 0, plane96);
+                          planes, st, l96 ? 1 : 0, plane96,
+                          x0_out ? x0_out + (size_t)n0 * (h / 2 + 1) * (w / 2 + 1) * 64 * bpc : nullptr);     // (U-Net: the conv map before the pool)
             prof_close(st, pi_);
             if (rc) return rc;
         }
@@ -1207,6 +1211,7 @@ int wsi_trunk_forward_tap(const wsi_trunk_weights* wt, const float* in_f32, cons
 static const int kUnetSkipC[5] = {256, 128, 64, 64, 0};      // encoder maps x3, x2, x1, x0 (and none for the last block)
 int g_unet_fuse_up = 1;                                  // A/B: wsi_conv_set_mode +65536 off
 int g_unet_tail = 1;                                     // A/B: wsi_conv_set_mode +2097152 off
+int g_unet_x0_fused = 1;                                 // A/B: wsi_conv_set_mode +8388608 off
 struct UnetPlan {
     size_t x0, cat[5], mid[5], out[5], total;
     int r_h[5], r_w[5], cx[5];                               // resolution of block L; channels of its upsampled input
@@ -1309,8 +1314,12 @@ int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights
     // encoder: the trunk with every stage output kept as an ordinary PF tensor (no phase-split hand-over) ...
     size_t off, stage_off[4];
     int stage;
+    // r05: on the product path (u8 slide, parity mode) the fused stem + pool kernel stores x0 = relu(bn1(conv1(x))) itself - the conv
+    // values it pools anyway, exact integer arithmetic - instead of a second, unfused stem conv (A/B: wsi_conv_set_mode +8388608 off)
+    const bool x0_fused = g_unet_x0_fused && !in_f32 && planes == 2 && wt->stem_w_u8 && wt->stem_b_u8 && wt->norm && g_stem_u8x && g_stem_fused &&
+                          g_stem_shared_weights;
     int rc = trunk_run(wt, in_f32, slide, slide_pitch_bytes, slide_h, slide_w, tile_xy, lut, n, cap, h, w, workspace, 8, st, p, off, stage,
-                       false, stage_off);
+                       false, stage_off, x0_fused ? dec + u.x0 : nullptr);
     if (rc) return rc;
     // ... plus x0 = relu(bn1(conv1(x))) before the max pool, which the fused stem kernel never writes: the unfused stem
     // conv (bf16 hi/lo arithmetic) into the fp32 scratch, then PF lines
@@ -1320,7 +1329,8 @@ int wsi_unet_forward(const wsi_trunk_weights* wt, const wsi_unet_decoder_weights
     a.origins = tile_xy; a.lut = lut; a.wpk = wt->stem_w; a.bias = wt->stem_b; a.out = (float*)(ws + p.stem_scratch);
     a.N = n; a.H = h; a.W = w; a.wpk_u8 = nullptr; a.bias_u8 = nullptr;
     const int pi = prof_open(st, 7, 0.0);                    // (glue: the unfused stem conv for the half-resolution skip x0)
-    if (g_unet_fuse_up) {                                    // r04: the conv kernel writes PF lines itself (was: f32 scratch + nhwc_to_pf pass)
+    if (x0_fused) {
+    } else if (g_unet_fuse_up) {                                    // r04: the conv kernel writes PF lines itself (was: f32 scratch + nhwc_to_pf pass)
         a.out_pf = dec + u.x0; a.out_planes = planes;
         rc = wsi_stem_dispatch(a, planes == 1 ? 1 : 2, st);
     } else {

@@ -243,12 +243,14 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* in, void
 //   carried row 2py-1 is register-local, the horizontal 3-max is two lane shuffles, results sit on
 //   odd lanes.  The normalised input lives in a 16-row LDS ring: 4 new rows are staged per step,
 //   one barrier per step.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 struct StemPoolArgs {
     StemArgs s;              // s.out unused
     void* out_pf;            // PF (H/4, W/4, 64)
     int rows_per_seg;        // pooled rows per workgroup
     int out96;               // OUT == 3: 96-byte output lines (common.h CONV_OUT96), line-planar:
     long long plane96;       // bytes from the 32-channel line plane of wave 0's channels to wave 1's (ConvArgs.plane96)
+    void* x0_pf;             // X0 kernels (U-Net): the conv output BEFORE the pool, relu(bn1(conv1(x))), as a PF tensor (H/2, W/2, 64), planes 2
 };
 
 constexpr int SP_COLS = 70;                  // input columns per strip (2*31 + 8: the widest lane's 16-byte read)
@@ -275,10 +277,15 @@ constexpr int STEM_I8_SCALE_OFFSET = 2 * 7 * 3 * 1024;           // float scale[
 // + matrix pipe 32 % of the SIMD time with the waves waiting 25 % of their lifetime - more waves, not fewer instructions,
 // is what the kernel lacks.
 constexpr int SP_RING_I8 = SP_RING * SP_COLS * 4;                       // ring bytes of the integer path (4 B per pixel)
-template <int PLANES, int OUT, int DIG = 0, int NSTRIP = 1>
+// X0 (r05, the U-Net's half-resolution skip): the kernel also stores every conv value it computes - the smp encoder's first feature map
+// x0 = relu(bn1(conv1(x))), which the pool consumes and r02-r04 recomputed with the unfused fp16-pair stem kernel (325 us per 128 tiles
+// of 256 x 256 beside this kernel's 227).  A strip's lanes 1..30 (odd layout) own conv columns 2 px0 .. 2 px0 + 29 - lane 0 is the
+// left neighbour's last column - and the carry-only first step of a segment owns nothing, so every conv pixel is stored exactly once.
+template <int PLANES, int OUT, int DIG = 0, int NSTRIP = 1, bool X0 = false>
 __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_kernel(StemPoolArgs A) {
     constexpr bool U8X = DIG > 0, WLDS = NSTRIP > 1;
     static_assert(!WLDS || U8X, "shared weights: integer path only");
+    static_assert(!X0 || (U8X && OUT == 2), "x0 output: integer path, fp16-pair lines");
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const StemArgs& a = A.s;
     const int tid = threadIdx.x & 127, lane = tid & 63;                 // tid: thread within the strip's wave pair
@@ -498,6 +505,9 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
         }
         // bias + ReLU + validity mask, vertical max with the carried row, keep row 2py+1 as the next carry
         float v[16];
+        float xv[2][4];                                                 // X0: four channels of the two conv rows
+        unsigned xq[2][2][4];                                           //     [row][group parity][hi0 hi1 lo0 lo1] packed pairs
+        (void)xv; (void)xq;
         if constexpr (U8X) {
             // Integer path: the carried row and the vertical max live in the RAW domain (the exact digit recombination, before the
             // channel's scale and shift).  scale > 0 (wsi_prepack_stem_u8), so x -> max(fma(x, scale, shift), 0) is monotone,
@@ -509,9 +519,44 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
                 if constexpr (DIG == 3) c = __builtin_fmaf((float)aq[mt][DIG - 1][r], 65536.0f, c);
                 return c;
             };
+            const bool x0_store = X0 && py >= py0 && col_ok && (even || (l31 >= 1 && l31 <= 30));
+            const PFGeom gx = pf_geom(a.N, Hc, Wc, 64);
+            char* const x0p = X0 ? (char*)A.x0_pf + ((size_t)(gx.G + n * gx.S + 2 * py * gx.P + (x0_store ? c0 + l31 : 0)) * 256 + wave * 128 + 16 * h) : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float c0 = raw(0, r), c1 = raw(1, r);
+                if constexpr (X0) {                                     // conv rows 2py, 2py + 1 themselves: scale, shift, ReLU, fp16 pair
+                    xv[0][r & 3] = __builtin_amdgcn_fmed3f(__builtin_fmaf(c0, sb_lds[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)],
+                                                                          sb_lds[64 + wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)]), 0.f, 65504.f);
+                    xv[1][r & 3] = __builtin_amdgcn_fmed3f(__builtin_fmaf(c1, sb_lds[wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)],
+                                                                          sb_lds[64 + wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3)]), 0.f, 65504.f);
+                    if ((r & 3) == 3) {
+                        const int g = r >> 2;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            f16x4 hi, lo;
+                            split_f16x4(xv[mt], hi, lo);
+                            const u32x2 hq = __builtin_bit_cast(u32x2, hi), lq = __builtin_bit_cast(u32x2, lo);
+                            xq[mt][g & 1][0] = hq[0]; xq[mt][g & 1][1] = hq[1]; xq[mt][g & 1][2] = lq[0]; xq[mt][g & 1][3] = lq[1];
+                        }
+                        if (g & 1) {
+                            // channels 8g' + 4h + i of the group pair (g - 1, g): lanes h = 0 give their second group for the partner's first, so
+                            // h = 0 holds eight consecutive channels 16 (g >> 1) + 0..7 and h = 1 the next eight: 16-byte stores
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) {
+                                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+                                             "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+                                             : "+v"(xq[mt][0][0]), "+v"(xq[mt][0][1]), "+v"(xq[mt][0][2]), "+v"(xq[mt][0][3]),
+                                               "+v"(xq[mt][1][0]), "+v"(xq[mt][1][1]), "+v"(xq[mt][1][2]), "+v"(xq[mt][1][3]));
+                                if (x0_store) {
+                                    char* o = x0p + (size_t)mt * gx.P * 256 + (g >> 1) * 32;
+                                    *(u32x4*)o = u32x4{xq[mt][0][0], xq[mt][0][1], xq[mt][1][0], xq[mt][1][1]};
+                                    *(u32x4*)(o + 64) = u32x4{xq[mt][0][2], xq[mt][0][3], xq[mt][1][2], xq[mt][1][3]};
+                                }
+                            }
+                        }
+                    }
+                }
                 const float m = fmaxf(fmaxf(carry[r], c0), c1);
                 carry[r] = c1;
                 const int ch = wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
@@ -611,10 +656,10 @@ __global__ __launch_bounds__(128 * NSTRIP, NSTRIP == 1 ? 2 : 3) void stem_pool_k
 }
 
 int g_stem_shared_weights = 1;                        // A/B: wsi_stem_set_mode(fused = 3) selects the one-strip form (weights in registers)
-int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96, long long plane96) {
+int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows_per_seg, hipStream_t st, int out96, long long plane96, void* x0_pf) {
     if (a.H % 4 || a.W % 4 || a.N <= 0 || planes < 1 || planes > 3 || rows_per_seg <= 0) return WSI_EINVAL;
     StemPoolArgs A;
-    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg; A.out96 = out96; A.plane96 = plane96;
+    A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg; A.out96 = out96; A.plane96 = plane96; A.x0_pf = x0_pf;
     if (out96 && plane96 <= 0) return WSI_EINVAL;
     const int Hp = a.H / 4, Wp = a.W / 4;
     const long long grid = (long long)a.N * (Wp <= 16 ? 1 : (Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);   // strips, see kernel
@@ -624,9 +669,13 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
     if (u8x && g_stem_shared_weights) {               // integer stem, two strips per workgroup, digit planes shared in LDS
         const size_t lds2 = 2 * SP_RING_I8 + 512 + 2 * 7 * 3 * 1024;
         const int grid2 = (int)((grid + 1) / 2);
+        if (x0_pf && planes != 2) return WSI_EINVAL;
         if (planes == 3) hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3, 2>), dim3(grid2), dim3(256), lds2, st, A);
+        else if (x0_pf) hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3, 2, true>), dim3(grid2), dim3(256), lds2, st, A);
         else hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3, 2>), dim3(grid2), dim3(256), lds2, st, A);
-    } else if (u8x && planes == 3)                    // integer stem, 24-bit weights in both modes (r02: the 16-bit form, DIG 2, costs mx margin)
+    } else if (x0_pf)
+        return WSI_EINVAL;                            // the x0 output exists in the shared-weights integer form only
+    else if (u8x && planes == 3)                      // integer stem, 24-bit weights in both modes (r02: the 16-bit form, DIG 2, costs mx margin)
         hipLaunchKernelGGL((stem_pool_kernel<2, 3, 3>), dim3((int)grid), dim3(128), lds, st, A);
     else if (u8x)
         hipLaunchKernelGGL((stem_pool_kernel<2, 2, 3>), dim3((int)grid), dim3(128), lds, st, A);
