@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument('--workload', choices=('cfg2', 'cfg3', 'cfg4', 'cfg5', 'seg'), default='cfg3',
                     help="seg: the dense per-pixel mode (predict_tumorbed mode='seg': ResNet-18 encoder + U-Net decoder), --seg-tiles tiles of 256x256 per step")
     ap.add_argument('--seg-tiles', type=int, default=512)
-    ap.add_argument('--seg-batch', type=int, default=128, help='seg: tiles per U-Net call (77 MB of workspace per tile)')
+    ap.add_argument('--seg-batch', type=int, default=512, help='seg: tiles per U-Net call (77 MB of workspace per tile; r05 sweep 128 / 256 / 512: 28.1 / 31.2 / 33.1 k patches/s)')
     ap.add_argument('--mode', choices=('parity', 'mx', 'speed'), default=None,
                     help='parity: fp16 hi + fp16 lo pair, 3 MFMA passes (logit error ~1e-5); mx: fp16 pass + MX-fp6 cross terms '
                          '(5e-4, inside the 1e-3 contract); speed: single-pass bf16 (2e-2, outside the contract).  Default: mx; for '
@@ -639,6 +639,28 @@ def run_rank(args):
             torch.cuda.synchronize()
             ts_ref.append(time.perf_counter() - r0)
         t_ref = float(np.median(ts_ref[1:]))
+        # ... and the bare engine followed by the stages the API call adds behind it, written out by hand: float64 map, dense stitch,
+        # exponent-span guard, softmax + threshold + arg-max with a device-resident mask, both u8 maps to the host
+        from wsi_segmentation_pipeline_amd import engine as EN
+        n_side = side * TILE
+        mask_dev = torch.ones((n_side, n_side), dtype=torch.uint8, device=dev)
+
+        def bare_pipeline():
+            pred_ = torch.zeros((4, n_side, n_side), dtype=torch.float64, device=dev)
+            lg_ = eng.forward_tiles(level0, sxy, TILE, TILE)
+            EN.stitch_add_dense(pred_, lg_, sxy)
+            EN.exponent_span(lg_)
+            cls_, _, heat_ = EN.softmax_threshold_argmax(pred_, [0., 0., 0., 0.], mask_dev, 'seg', want_probs=False)
+            return UE._to_host(heat_, cls_)
+        ts_pipe = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            bare_pipeline()
+            torch.cuda.synchronize()
+            ts_pipe.append(time.perf_counter() - r0)
+        t_pipe = float(np.median(ts_pipe[1:]))
+        del mask_dev
         model = UNetSeg(4, precision=args.mode)
         model.load_state_dict(usd)
         model = model.to(dev).eval()
@@ -651,7 +673,6 @@ def run_rank(args):
         ma = myargs.args
         saved = {k: getattr(ma, k) for k in ('scan_level', 'scan_resize', 'num_classes', 'class_probs', 'tile_w', 'tile_h', 'tile_stride_w',
                                              'tile_stride_h', 'wsi_mask_pth', 'val_save_pth')}
-        n_side = side * TILE
         with tempfile.TemporaryDirectory() as td:
             ma.scan_level, ma.scan_resize, ma.num_classes, ma.class_probs = 0, 1, 4, [0., 0., 0., 0.]
             ma.tile_w = ma.tile_h = ma.tile_stride_w = ma.tile_stride_h = TILE
@@ -685,6 +706,10 @@ def run_rank(args):
                                                   'note': 'UNetEngine.forward_tiles of the timed region (logits only: no stitch, no softmax, no maps to the host), one call + one '
                                                           'synchronisation per slide, right before the API calls (median of 3 after one warm-up)'},
                'vs_bare_engine_one_slide_per_call': round((n_api / t_api) / (args.seg_tiles / t_ref), 4),
+               'bare_pipeline_one_slide_per_call': {'value': round(args.seg_tiles / t_pipe, 1), 'ms_per_slide': round(t_pipe * 1e3, 3), 'tiles': args.seg_tiles,
+                                                    'note': 'the same engine call followed by what the API adds behind it, written by hand against the engine module: float64 '
+                                                            'map, dense stitch, exponent-span guard, softmax + threshold + arg-max (device-resident mask), both u8 maps to the host'},
+               'vs_bare_pipeline_one_slide_per_call': round((n_api / t_api) / (args.seg_tiles / t_pipe), 4),
                'call': "utils.eval.predict_tumorbed(UNetSeg(4, precision=%r), utils.dataset.Dataset_wsis(...), ep, mode='seg', save=False)" % args.mode,
                'timed': 'after the timed region: median of 3 calls after one warm-up call; includes the mask upload, the float64 dense stitch of every '
                         '(4, 256, 256) block, the exponent-span guard, softmax + threshold + argmax on the %d x %d map, u8 maps to the host' % (n_side, n_side),

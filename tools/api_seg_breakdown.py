@@ -20,7 +20,7 @@ for key in ('decoder.final_conv.weight', 'decoder.final_conv.bias'):
 model = UNetSeg(4, precision=sys.argv[1] if len(sys.argv) > 1 else 'parity')
 model.load_state_dict(usd)
 model = model.to(dev).eval()
-model.hip_engine(dev).max_batch = 128
+model.hip_engine(dev).max_batch = 512
 level0 = torch.randint(0, 256, (side * TILE, side * TILE, 3), dtype=torch.uint8, device=dev)
 acc = collections.OrderedDict()
 undo = []
@@ -65,6 +65,26 @@ with tempfile.TemporaryDirectory() as td:
     dsw = UD.Dataset_wsis({'bench.svs': sl}, {'ph': TILE, 'pw': TILE, 'sh': TILE, 'sw': TILE}, bs=ma.batch_size)
     for mod, name, f in undo:
         setattr(mod, name, f)
+    # free-running API calls against the hand-written pipeline on the same engine
+    eng = model.hip_engine(dev)
+    xy_all = torch.tensor(np.asarray(dsw.wsis['bench.svs']['iterator'].dataset.tile_xy), dtype=torch.int32, device=dev)
+    mask_dev = torch.ones((side * TILE, side * TILE), dtype=torch.uint8, device=dev)
+    for rep in range(4):
+        sl = S.ArraySlide([level0], [1.0]); sl.level_dimensions = ((side * TILE, side * TILE),); sl.name = 'bench.svs'
+        d2 = UD.Dataset_wsis({'bench.svs': sl}, {'ph': TILE, 'pw': TILE, 'sh': TILE, 'sw': TILE}, bs=ma.batch_size)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        UE.predict_tumorbed(model, d2, 0, mode='seg', save=False)
+        torch.cuda.synchronize(); t_api = time.perf_counter() - t0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        pred_ = torch.zeros((4, side * TILE, side * TILE), dtype=torch.float64, device=dev)
+        lg_ = eng.forward_tiles(level0, xy_all, TILE, TILE)
+        E.stitch_add_dense(pred_, lg_, xy_all)
+        E.exponent_span(lg_)
+        c_, _, h_ = E.softmax_threshold_argmax(pred_, [0., 0., 0., 0.], mask_dev, 'seg', want_probs=False)
+        UE._to_host(h_, c_)
+        torch.cuda.synchronize(); t_pipe = time.perf_counter() - t0
+        del pred_, lg_, c_, h_
+        print('free-running rep %d: API call %.2f ms | hand-written pipeline %.2f ms (%d tiles)' % (rep, t_api * 1e3, t_pipe * 1e3, xy_all.shape[0]))
     pr = cProfile.Profile()
     torch.cuda.synchronize()
     pr.enable()

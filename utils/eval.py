@@ -97,8 +97,8 @@ def _dense_batches(model, it, scan, dev, forward):
         level = scan.device_level(args.scan_level, dev)
         lo, hi = it.span
         ph, pw = ds.params.ph, ds.params.pw
-        nb = max(1, -(-(hi - lo) // eng._batch(ph, pw)))
-        mb = -(-(hi - lo) // nb)                             # equal batches: no short last batch (528 tiles: 5 x 106, not 4 x 128 + 16)
+        nb = max(1, int(np.ceil((hi - lo) / eng._batch(ph, pw) - 0.25)))     # (a quarter over the tuned batch still runs as ONE batch)
+        mb = -(-(hi - lo) // nb)                             # equal batches: no short last batch
         xy_dev = S._upload(ds.tile_xy[lo:hi], torch.int32, dev)     # one asynchronous upload: the host keeps enqueuing batches ahead of the GPU
         for i in range(0, hi - lo, mb):
             yield np.ascontiguousarray(ds.tile_xy[lo + i:min(lo + i + mb, hi)]), eng.forward_tiles(level, xy_dev[i:i + mb], ph, pw)
@@ -129,7 +129,11 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
             map_hw = scan.level_dimensions[ref_level][::-1]
             m = scan.level_downsamples[args.scan_level] / scan.level_downsamples[ref_level]
             # (pinned staging + asynchronous copy: a pageable-memory copy would block the host until everything enqueued so far has run)
-            mask = S._upload(entry['mask'], torch.as_tensor(entry['mask']).dtype, dev) if entry.get('mask') is not None else None
+            def upload_mask():
+                return S._upload(entry['mask'], torch.as_tensor(entry['mask']).dtype, dev) if entry.get('mask') is not None else None
+            # (mode 'seg' uploads its mask - the size of the scan level there - AFTER the tile loop is enqueued: pinning 35 MB of host
+            # memory costs the host 5-13 ms, during which the GPU would sit idle at the head of the call; r05 profiles/r05_api_seg_breakdown.txt)
+            mask = upload_mask() if mode == 'cls' else None
             if mode == 'cls' and isinstance(model, SlideClassifierModel):
                 # fused fast path: the stem kernel reads the HBM-resident slide directly
                 level = scan.device_level(args.scan_level, dev)
@@ -176,6 +180,7 @@ def predict_tumorbed(model, dataset, ep, mode='seg', rank=0, world=1, save=True)
                     span_lo = sp[0:1] if span_lo is None else torch.minimum(span_lo, sp[0:1])
                     span_hi = sp[1:2] if span_hi is None else torch.maximum(span_hi, sp[1:2])
                 span = torch.cat((span_lo, span_hi)) if span_lo is not None else None
+                mask = upload_mask()
                 if world > 1:
                     txy_all = np.concatenate(my_txy) if my_txy else np.zeros((0, 2), np.int64)
                     pred = S.gather_map_bands(pred, txy_all, dy, dx, rank, world, dst=0)

@@ -503,9 +503,22 @@ int wsi_unet_tail_dispatch(const void* x4, const void* blob, int n, int h, int w
     if ((size_t)pf_alloc_pixels(n, h, w) * 128 > (size_t)0x7fffffff) return WSI_EINVAL;     // 32-bit buffer offsets
     TailArgs a;
     a.in = (const char*)x4; a.gl = pf_geom(n, h, w, 32); a.blob = (const char*)blob; a.out = logits; a.classes = classes;
-    // bands: enough workgroups for the 256 CUs, whole low-resolution rows, each band at least 8 rows (the two overlap steps)
+    // Bands per image: one workgroup per CU runs a whole band, so the grid should fill whole rounds of the chip's CUs (528 images in
+    // one band each = three rounds on 256 CUs, the last one 6 % full) while every band pays two overlap steps: pick the power of two
+    // that maximises (fill of the last round) x rows / (rows + 2), bands of at least 8 low-resolution rows
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     int bands = 1;
-    while (n * bands < 256 && h % (bands * 2) == 0 && h / (bands * 2) >= 8) bands *= 2;
+    double best = 0.0;
+    for (int b = 1; h % b == 0 && h / b >= 8; b *= 2) {
+        const long long wgs = (long long)n * b, rounds = (wgs + cus - 1) / cus;
+        const double score = (double)wgs / (double)(rounds * cus) * (double)(h / b) / (double)(h / b + 2);
+        if (score > best * 1.02) { best = score; bands = b; }      // (ties and near-ties: the fewer bands)
+    }
     a.bands = bands; a.rows_per_band = h / bands;
     if (g_unet_tail_form == 2 && (w == 32 || w == 64 || w == 128)) {
         const size_t lds2 = wsi_unet_tail2_lds_bytes(w);
