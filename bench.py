@@ -297,11 +297,26 @@ def run_rank(args):
         cs_, c1_ = (int(v) for v in args.chunks.split(','))
         per = min(args.batch, per_rank_units)
         launches_per_step = nb * (16 + (-(-per // cs_) if cs_ else 1) + 4 * (-(-per // c1_) if c1_ else 1) + (-(-per // c1_) if c1_ and cs_ else 0))
+    # The cyclic garbage collector is switched off for the timed region, as `timeit` does: r05 found a generation-2 collection of
+    # ~45 ms (the tile lists and bag index lists are millions of Python objects) landing INSIDE the five timed steps of cfg4 whenever
+    # the import graph grew by a module - 1.52 M crops/s measured as 1.24 M, with identical kernels and an identical GPU timeline
+    # (tools/cfg4_steps.py, profiles/r05_bench_gc_pause.txt).  WSI_BENCH_GC=on keeps it running.
+    import gc
+    gc_off = os.environ.get('WSI_BENCH_GC') != 'on'
+    if gc_off:
+        gc.collect()
+        gc.disable()
     t0 = time.perf_counter()
+    step_marks = []                                         # WSI_BENCH_STEP_TIMES=1: host time at which each step's enqueue returned (diagnosis)
     for _ in range(args.steps):
         out = step()
+        step_marks.append(time.perf_counter() - t0)
     fence()
     dt = time.perf_counter() - t0
+    if gc_off:
+        gc.enable()
+    if os.environ.get('WSI_BENCH_STEP_TIMES') == '1' and rank == 0:
+        print('step enqueue returns (ms): %s | fence %.1f' % (' '.join('%.1f' % (m * 1e3) for m in step_marks), dt * 1e3), file=sys.stderr)
     # Per-kernel leg (roofline objects): the SAME steps once more, right after the timed region, with ONE batch in flight and HIP
     # events on the launch stream around every conv / stem launch (wsi_prof_begin/_end).  r01-r03 took these events inside the
     # timed region and therefore benchmarked one batch in flight; two in flight are ~3 % faster, and their overlapping launches
@@ -789,6 +804,10 @@ def run_rank(args):
                        'parallelism': parallelism, 'batches_in_flight': max(1, args.streams)},
             'roofline': roofline, 'roofline_layer1': roofline_l1, 'roofline_stem': roofline_stem, 'roofline_bf16': roofline_bf16, 'cpu_baseline': cpu_baseline,
             'contract': contract, 'parity': parity_leg, 'api': api,
+            'timing': {'python_gc': 'disabled inside the timed region (timeit convention; gc.collect() right before it)' if gc_off else 'enabled',
+                       'longest_step_ms': round(max(b - a_ for a_, b in zip([0.0] + step_marks[:-1], step_marks)) * 1e3, 3),
+                       'note': 'longest_step_ms = the largest gap between the host returns of two consecutive steps (steps that end in a host read - cfg4, cfg5 - are '
+                               'synchronous, so this is the slowest step; slide steps return after enqueueing)'},
             'kernels': per_kind,
             'kernel_leg': ({'ms_per_step': round(prof_dt / args.steps * 1e3, 3), 'steps': args.steps, 'batches_in_flight': 1,
                             'timed': 'separate pass right after the timed region: HIP events on the launch stream around every conv / stem launch'}
