@@ -662,6 +662,8 @@ int wsi_stem_pool_dispatch(const StemArgs& a, void* out_pf, int planes, int rows
     A.s = a; A.out_pf = out_pf; A.rows_per_seg = rows_per_seg; A.out96 = out96; A.plane96 = plane96; A.x0_pf = x0_pf;
     if (out96 && plane96 <= 0) return WSI_EINVAL;
     const int Hp = a.H / 4, Wp = a.W / 4;
+    if (rows_per_seg > Hp) rows_per_seg = Hp;        // (a 64 x 64 crop has 16 pooled rows: the kernel makes rows_per_seg + 1 barrier trips whatever the map holds)
+    A.rows_per_seg = rows_per_seg;
     const long long grid = (long long)a.N * (Wp <= 16 ? 1 : (Wp + 14) / 15) * ((Hp + rows_per_seg - 1) / rows_per_seg);   // strips, see kernel
     if (grid > 0x7fffffffLL) return WSI_EINVAL;
     const bool u8x = a.mode == 1 && a.wpk_u8 && a.bias_u8 && planes >= 2;
