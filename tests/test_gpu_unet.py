@@ -289,3 +289,28 @@ def test_stem_kernel_stores_the_half_resolution_skip_itself(dev, sd, shape):
     with torch.no_grad():
         ref = U.unet_forward(sd, x)
     assert float((fused.cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()) / 16.0)
+
+
+@pytest.mark.parametrize('classes', [1, 2, 3])
+def test_fused_decoder_tail_with_fewer_classes(dev, classes):
+    """The fused tail pads the head to four classes in its weight blob and stores only the real ones: 1-3 classes against the three launches."""
+    from wsi_segmentation_pipeline_amd import native
+    from wsi_segmentation_pipeline_amd.unet import UNetEngine
+    lib = native.load()
+    sdc = W.make_unet_state_dict(9, classes)
+    x = R.normalize_u8(W.make_u8_patches(77 + classes, (2, 3, 64, 128)))
+    sdc = _scaled_to_logit(sdc, x)
+    eng = UNetEngine(sdc, dev, planes=2)
+    assert eng.dw.tail_w
+    fused = eng.forward_f32(x.to(dev))[0]
+    assert tuple(fused.shape) == (2, classes, 64, 128)
+    lib.wsi_conv_set_mode(1 + 2097152)
+    try:
+        plain = eng.forward_f32(x.to(dev))[0]
+    finally:
+        lib.wsi_conv_set_mode(1)
+    d = float((fused - plain).abs().max())
+    assert 0 < d <= 2e-5 * max(float(plain.abs().max()), 1.0), d
+    with torch.no_grad():
+        ref = U.unet_forward(sdc, x)
+    assert float((fused.cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()) / 16.0)
