@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0
 # BASELINE.json's metric, verbatim
 METRIC = 'patches/sec (256×256×3) whole-slide inference, 1/2/4/8 MI355X + CPU ref'
 KIND_NAMES = {1: 'conv3x3_s1', 5: 'conv3x3_s1_layer1', 2: 'conv3x3_s2', 3: 'conv1x1_s2', 4: 'stem_maxpool',
-              6: 'unet_decoder_conv3x3', 7: 'unet_glue', 8: 'unet_head_1x1'}
+              6: 'unet_decoder_conv3x3', 7: 'unet_glue', 8: 'unet_head_1x1', 10: 'unet_tail_fused'}
 SEG_DECODER_GFLOP = 6.04                  # decoder 3x3 convs per 256x256 tile over REAL channels (encoder trunk 3.63 + stem 0.31)
 SEG_TILE_GFLOP = 3.63 + 0.31 + 6.04
 
@@ -740,14 +740,28 @@ def run_rank(args):
     if args.workload == 'seg' and rank == 0:
         # roofline of the seg path's dominant kernels = the ten 3x3 convs of the decoder (same conv3x3s1 kernels as the trunk on PF
         # tensors): algorithmic FLOPs over REAL channels (6.04 GFLOP per tile) / their summed HIP-event time in the kernel leg
-        k6 = per_kind.get('unet_decoder_conv3x3')
+        k6, k10 = per_kind.get('unet_decoder_conv3x3'), per_kind.get('unet_tail_fused')
         if k6:
-            tf = SEG_DECODER_GFLOP * 1e9 * args.seg_tiles * args.steps / (k6['avg_ms'] * k6['launches'] * 1e-3) / 1e12
-            roofline = {'kernel': 'U-Net decoder 3x3 convs (10 launches per batch: conv3x3s1_wide_kernel / conv3x3s1_slab3_kernel on 16..256-wide maps)',
+            dec_ms = k6['avg_ms'] * k6['launches'] + (k10['avg_ms'] * k10['launches'] if k10 else 0.0)
+            tf = SEG_DECODER_GFLOP * 1e9 * args.seg_tiles * args.steps / (dec_ms * 1e-3) / 1e12
+            roofline = {'kernel': 'U-Net decoder 3x3 convs (per batch: 8 launches of conv3x3s1_wide_kernel / conv3x3s1_slab3_kernel on 16..128-wide maps + the fused '
+                                  'last block and head, unet_tail2_kernel; three-launch tail: 10 launches)' if k10 else
+                                  'U-Net decoder 3x3 convs (10 launches per batch: conv3x3s1_wide_kernel / conv3x3s1_slab3_kernel on 16..256-wide maps)',
                         'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
-                        'traffic': None, 'avg_launch_ms': round(k6['avg_ms'], 4), 'share_of_step': k6['share_of_step'],
+                        'traffic': None, 'avg_launch_ms': round(dec_ms / (k6['launches'] + (k10['launches'] if k10 else 0)), 4),
+                        'share_of_step': k6['share_of_step'] + (k10['share_of_step'] if k10 else 0.0),
                         'algorithmic_gflop_per_tile': SEG_DECODER_GFLOP, 'precision_mode': args.mode,
                         'whole_path_tflops': round(SEG_TILE_GFLOP * 1e9 * units_per_step * args.steps / dt / 1e12, 2)}
+            if k10:
+                # the fused tail alone: FLOPs of the reference formulation over real channels (9 * (32 * 16 + 16 * 16) + 16 * 4 MACs per pixel), its
+                # HBM traffic from the PMC passes of profiles/r05_traffic_seg.txt (2.15 MB read + 1.05 MB written per tile = the algorithmic bytes)
+                roofline['tail'] = {'kernel': 'unet_tail2_kernel (nearest x2 upsample + conv 32->16 + conv 16->16 + 1x1 head, one launch)', 'bound': 'mfma',
+                                    'achieved': round(k10['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(k10['tflops'] / PEAK_BF16_TFLOPS, 4),
+                                    'avg_launch_ms': round(k10['avg_ms'], 4), 'share_of_step': k10['share_of_step'],
+                                    'traffic': {'read_bytes_per_tile': 2.15e6, 'write_bytes_per_tile': 1.05e6, 'algorithmic_bytes_per_tile': 128 * 128 * 128 + 4 * 256 * 256 * 4,
+                                                'source': 'profiles/r05_traffic_seg.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)'},
+                                    'note': 'three passes of fp16 MFMA per product (parity mode) on polyphase-packed tiles: 36 MFMAs of 32 cycles per 32 output pixels = '
+                                            '124 us of matrix-pipe time per 128 tiles'}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import unet_oracle as UO                 # the checker, never the thing measured above
             from oracle import resnet_oracle as R

@@ -1286,8 +1286,7 @@ static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& 
         x = dec + u.out[L];
     }
     if (tail) {
-        // (kind 6: the decoder-conv record carries the unfused formulation's FLOPs over the stored channels, like the four blocks above)
-        const int pt = prof_open(st, 6, 2.0 * n * u.r_h[4] * u.r_w[4] * 9.0 * ((double)dw->cin[8] * dw->cout[8] + (double)dw->cin[9] * dw->cout[9]));
+        const int pt = prof_open(st, 10, 2.0 * n * u.r_h[4] * u.r_w[4] * (9.0 * (32.0 * 16.0 + 16.0 * 16.0) + 16.0 * dw->classes));    // kind 10: the reference formulation's FLOPs over REAL channels
         if (!rc) rc = wsi_unet_tail_dispatch(x, dw->tail_w, n, u.r_h[3], u.r_w[3], dw->classes, logits_out, st);
         prof_close(st, pt);
         return rc;
