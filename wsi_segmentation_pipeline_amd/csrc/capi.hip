@@ -1260,7 +1260,8 @@ static int unet_decoder_run(const wsi_unet_decoder_weights* dw, const UnetPlan& 
     // r05: parity mode runs the last block and the head as ONE kernel (tail.hip) when the caller prepacked its weights
     // (wsi_unet_tail_prepack -> dw->tail_w) and the map is at most 256 wide; A/B: wsi_conv_set_mode +2097152 off
     const bool tail = planes == 2 && dw->tail_w && g_unet_tail && u.cx[4] == 32 && kUnetSkipC[4] == 0 && dw->classes <= 4 &&
-                      u.r_w[3] % 32 == 0 && u.r_w[3] <= 128;
+                      u.r_w[3] % 32 == 0 && u.r_w[3] <= 128 &&
+                      (size_t)pf_alloc_pixels(n, u.r_h[3], u.r_w[3]) * 128 <= (size_t)0x7fffffff;      // (32-bit buffer offsets into x4: ~1000 tiles of 256 x 256)
     for (int L = 0; L < (tail ? 4 : 5) && !rc; ++L) {
         const int H = u.r_h[L], W = u.r_w[L], cin = dw->cin[2 * L], cout = dw->cout[2 * L];
         // r04: the block's first conv reads the low-resolution tensor and the skip directly (ConvArgs.in_up: nearest x2 upsample +
