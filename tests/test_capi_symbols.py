@@ -157,3 +157,80 @@ def test_prepack_conv_mode3_fp6_planes(lib):
                         step = 0.5 if abs(x) / scale >= 4 else 0.25 if abs(x) / scale >= 2 else 0.125
                         worst = max(worst, abs(q - x) / (step * scale))
     assert worst <= 0.5 + 1e-6
+
+
+def test_unet_tail_prepack_is_the_polyphase_sum(lib):
+    """wsi_unet_tail_prepack (host side of csrc/tail.hip): decoding the fp16 hi + lo fragments and undoing the per-channel power-of-two
+    scale gives, per output parity (py, px) and low-resolution offset, the SUM of the 3x3 taps whose nearest-upsampled source falls on
+    that offset (BN scale folded) - and running that 2 x 3-tap filter bank on a low-resolution image equals the 3x3 conv on its x2
+    nearest upsampling.  conv2's fragments: rows 0-15 = output row k (dy = input row), rows 16-31 = output row k + 1 (dy = input row - 1)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    cin, cmid, classes = 32, 16, 3
+    w1 = rng.normal(0, 0.2, (cmid, cin, 3, 3)).astype(np.float32)
+    w2 = rng.normal(0, 0.3, (cmid, cmid, 3, 3)).astype(np.float32)
+    bn = [[rng.uniform(0.5, 1.5, cmid).astype(np.float32), rng.normal(0, 0.1, cmid).astype(np.float32),
+           rng.normal(0, 0.1, cmid).astype(np.float32), rng.uniform(0.5, 1.5, cmid).astype(np.float32)] for _ in range(2)]
+    hw = rng.normal(0, 1, (classes, cmid)).astype(np.float32)
+    hb = rng.normal(0, 1, classes).astype(np.float32)
+    blob = np.zeros(lib.wsi_unet_tail_prepack_bytes(), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.wsi_unet_tail_prepack(p(w1), *[p(a) for a in bn[0]], p(w2), *[p(a) for a in bn[1]], 1e-5, p(hw), p(hb), cin, cmid, classes, p(blob)) == 0
+    assert lib.wsi_unet_tail_prepack(p(w1), *[p(a) for a in bn[0]], p(w2), *[p(a) for a in bn[1]], 1e-5, p(hw), p(hb), 64, cmid, classes, p(blob)) == -22
+    fl = blob[(48 + 24) * 1024:].view(np.float32)
+    sc = [bn[j][0].astype(np.float64) / np.sqrt(bn[j][3].astype(np.float64) + 1e-5) for j in range(2)]
+    sh = [bn[j][1].astype(np.float64) - bn[j][2].astype(np.float64) * sc[j] for j in range(2)]
+    assert np.allclose(fl[16:32], sh[0], rtol=1e-6, atol=1e-7) and np.allclose(fl[48:64], sh[1], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(fl[64:64 + 64].reshape(4, 16)[:classes], hw) and np.array_equal(fl[128:128 + classes], hb) and not fl[64 + 16 * classes:128].any()
+    frags = blob[:(48 + 24) * 1024].view(np.float16).astype(np.float64).reshape(-1, 64, 8)       # [fragment][lane][j]
+
+    def conv1_weight(py, t, row, ci):                            # hi + lo of A row `row`, input channel ci, tap t of parity class py
+        base = (py * 6 + t) * 4
+        f, lane, j = ci // 16, row + 32 * ((ci % 16) // 8), ci % 8
+        return frags[base + f, lane, j] + frags[base + 2 + f, lane, j]
+    wsets = {0: ([0], [1, 2]), 1: ([0, 1], [2])}                 # parity -> taps d feeding (first, second) low-resolution offset
+    got = np.zeros((2, 2, 2, 3, cmid, cin))                     # [py][px][a][ox index][c][ci]
+    for py in range(2):
+        for t in range(6):
+            for row in range(32):
+                px, c = row // 16, row % 16
+                for ci in range(cin):
+                    got[py, px, t // 3, t % 3, c, ci] = conv1_weight(py, t, row, ci) * fl[c]
+    wf = (w1.astype(np.float64) * sc[0][:, None, None, None]).astype(np.float32).astype(np.float64)
+    for py in range(2):
+        for px in range(2):
+            for a_ in range(2):
+                for oxi in range(3):
+                    b_ = oxi - px
+                    exp = np.zeros((cmid, cin))
+                    if 0 <= b_ <= 1:
+                        for dy in wsets[py][a_]:
+                            for dx in wsets[px][b_]:
+                                exp += wf[:, :, dy, dx]
+                    assert np.abs(got[py, px, a_, oxi] - exp).max() <= 2e-6 * np.abs(wf).max(), (py, px, a_, oxi)
+    # the filter bank on a low-resolution image == the 3x3 conv on its nearest x2 upsampling (the identity the kernel rests on)
+    x = torch.from_numpy(rng.normal(0, 1, (1, cin, 6, 7)))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), torch.from_numpy(wf), padding=1)
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.zeros_like(ref)
+    for py in range(2):
+        for px in range(2):
+            acc = 0
+            for a_ in range(2):
+                for oxi in range(3):
+                    oy, ox = py - 1 + a_, oxi - 1
+                    acc = acc + torch.einsum('oc,nchw->nohw', torch.from_numpy(got[py, px, a_, oxi]), xp[:, :, 1 + oy:1 + oy + 6, 1 + ox:1 + ox + 7])
+            out[:, :, py::2, px::2] = acc
+    assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # conv2: 12 taps = 4 input rows x 3 columns, two output rows per tile
+    w2f = (w2.astype(np.float64) * sc[1][:, None, None, None]).astype(np.float32).astype(np.float64)
+    for t in range(12):
+        for row in range(32):
+            rs, c = row // 16, row % 16
+            dy, dx = t // 3 - rs, t % 3
+            for ci in range(cmid):
+                lane, j = row + 32 * (ci // 8), ci % 8
+                v = (frags[48 + t * 2, lane, j] + frags[48 + t * 2 + 1, lane, j]) * fl[32 + c]
+                exp = w2f[c, ci, dy, dx] if 0 <= dy <= 2 else 0.0
+                assert abs(v - exp) <= 2e-6 * np.abs(w2f).max(), (t, row, ci)
